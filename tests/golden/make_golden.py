@@ -585,7 +585,7 @@ def gen_greedy():
 def main():
     os.makedirs("/tmp/mssr_golden", exist_ok=True)
     which = sys.argv[1:] or ["ops", "modules", "phases", "greedy"]
-    meta = dict(torch=torch.__version__, note="generated from /root/reference by tests/golden/make_golden.py")
+    meta = dict(torch=str(torch.__version__), note="generated from /root/reference by tests/golden/make_golden.py")
     for name in which:
         data = {"ops": gen_ops, "modules": gen_modules, "phases": gen_phases, "greedy": gen_greedy}[name]()
         data["_meta"] = meta
