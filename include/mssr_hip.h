@@ -1,0 +1,144 @@
+/*
+ * mssr_hip.h -- C ABI of libmssr_hip.so: the MI355X (gfx950) kernels behind the MSSRNet
+ * transformer training-step hot path.
+ *
+ * The reference (OldBirdAZ/mssrnet_style_transfer) has no FFI on this path: its five L1
+ * files call stock ATen ops.  Each entry point below replaces one such op chain; the
+ * comment on it cites the reference lines it stands in for.  The Python host side
+ * (mssrnet_style_transfer_amd/_lib.py) binds these with ctypes; INTEGRATION.md shows the
+ * binding.  Conventions:
+ *   - every pointer is a DEVICE pointer unless it says "host";
+ *   - `dtype`: MSSR_F32 or MSSR_BF16 = element type of activations ("void*" tensors);
+ *     LayerNorm gains/biases, Linear biases, statistics and parameter gradients are float;
+ *   - `stream` is a hipStream_t (NULL = the default stream); calls only enqueue work;
+ *   - return value MSSR_OK (0) or an error code; mssr_last_error() gives the message
+ *     (thread-local).  Shape / alignment violations are rejected before anything is launched;
+ *   - no entry point allocates or frees device memory; scratch is passed in by the caller.
+ */
+#ifndef MSSR_HIP_H
+#define MSSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { MSSR_F32 = 0, MSSR_BF16 = 1 };
+enum { MSSR_OK = 0, MSSR_ERR_ARG = 1, MSSR_ERR_LAUNCH = 2, MSSR_ERR_UNSUPPORTED = 3 };
+
+const char* mssr_last_error(void);
+int mssr_abi_version(void);
+
+/* ---------------------------------------------------------------- LayerNorm (eps inside) --
+ * Replaces nn.LayerNorm(d, eps=1e-6): onmt/encoders/transformer.py:34,101,
+ * onmt/decoders/transformer.py:69-70,244, onmt/modules/position_ffn.py:20,
+ * onmt/style_generator_builder.py:529.  One wave64 per row; rows are contiguous (stride d).
+ * d must be a multiple of 4 and <= 4096. */
+int mssr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y,
+                       float* mean, float* rstd, int64_t rows, int d, float eps, int dtype,
+                       void* stream);
+/* Number of float rows of `partial` scratch (each of width d) bwd / bwd_bwd need per output. */
+int mssr_layernorm_partial_rows(int64_t rows);
+/* dx, dgamma[d], dbeta[d] from dy.  partial: float[2 * partial_rows * d]. */
+int mssr_layernorm_bwd(const void* dy, const void* x, const float* gamma, const float* mean,
+                       const float* rstd, void* dx, float* dgamma, float* dbeta, float* partial,
+                       int64_t rows, int d, int dtype, void* stream);
+/* Backward of mssr_layernorm_bwd (the WGAN-GP double-backward, onmt/trainer_wgan_wh.py:
+ * 1247-1250,1315-1318): given ggx = dL/d(dx), ggg = dL/d(dgamma) and ggb = dL/d(dbeta) (either
+ * of the latter two may be NULL) produce g_dy = dL/d(dy), g_x = dL/dx and g_gamma[d] = dL/dgamma.
+ * partial: float[partial_rows * d]. */
+int mssr_layernorm_bwd_bwd(const void* ggx, const float* ggg, const float* ggb, const void* dy,
+                           const void* x, const float* gamma, const float* mean, const float* rstd,
+                           void* g_dy, void* g_x, float* g_gamma, float* partial, int64_t rows,
+                           int d, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------- dense GEMM -----
+ * C[z] = epilogue(alpha * A[z] . B[z]) for z in [0, batch_outer*batch_inner).
+ * Replaces nn.Linear / torch.matmul on the path: the Q/K/V/out projections
+ * (onmt/modules/multi_headed_attn.py:60-68,134-136,150-164,215), scores and context products
+ * (:189,205), FFN (onmt/modules/position_ffn.py:18-19,35-36), the soft-embedding product
+ * (onmt/modules/embeddings.py:280), the generator Linear (onmt/model_builder.py:181) and every
+ * backward of them.  MFMA: bf16 -> v_mfma_f32_16x16x32_bf16, f32 -> v_mfma_f32_16x16x4_f32,
+ * fp32 accumulate.
+ * A is addressed as [m,k] with element strides (a_rs, a_cs); B as [k,n] with (b_rs, b_cs);
+ * one of each pair must be 1.  C, residual and gate are row-major with leading dimensions
+ * ldc / ldr / ldg.  Batch z = zo*batch_inner + zi is offset by zo*x_bo + zi*x_bi elements.
+ * epilogue: v = alpha*acc (+ bias[n]) ; relu ? max(v,0) ; (+ residual) ; gate ? v*(gate>0) ;
+ *           (+ beta*C_old).  */
+typedef struct {
+    const void* a;
+    const void* b;
+    void* c;
+    const float* bias;
+    const void* residual;
+    const void* gate;
+    int64_t m, n, k;
+    int64_t a_rs, a_cs, b_rs, b_cs, ldc, ldr, ldg;
+    int64_t batch_outer, batch_inner;
+    int64_t a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;   /* residual / gate share C's batch strides */
+    float alpha, beta;
+    int relu;
+    int in_dtype;    /* dtype of A, B, residual, gate */
+    int out_dtype;   /* dtype of C */
+} mssr_gemm_desc;
+int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
+
+/* --------------------------------------------------------------------- row softmax --------
+ * y = softmax(scale * x) along the last axis, optionally masked, optionally log-softmax.
+ * Replaces scores.float().masked_fill(mask,-1e18) -> softmax (multi_headed_attn.py:195-202),
+ * F.softmax(logits / T) in the soft decode (onmt/train_and_translate.py:115) and the
+ * generator's LogSoftmax (onmt/model_builder.py:179).  Computes in fp32.
+ * Rows: r in [0, rows); x row r at x + r*ldx, y row at y + r*ldy.
+ * mask (uint8, nonzero = masked -> score replaced by -1e18) may be NULL; the mask row of r is
+ * mask + (r / rows_per_batch)*mask_bs + (r % q_len)*mask_qs. */
+int mssr_softmax_fwd(const void* x, void* y, const uint8_t* mask, int64_t rows, int n, int64_t ldx,
+                     int64_t ldy, int64_t rows_per_batch, int64_t q_len, int64_t mask_bs,
+                     int64_t mask_qs, float scale, int log_mode, int in_dtype, int out_dtype,
+                     void* stream);
+/* dx = scale * y*(dy - sum(y*dy))   (log_mode: scale * (dy - exp(y)*sum(dy))). */
+int mssr_softmax_bwd(const void* y, const void* dy, void* dx, int64_t rows, int n, int64_t ldy,
+                     int64_t lddy, int64_t lddx, float scale, int log_mode, int y_dtype,
+                     int dy_dtype, int dx_dtype, void* stream);
+/* Backward of mssr_softmax_bwd w.r.t. y (softmax mode): given g = dL/d(dx):
+ *   g_y = scale * ( g*(dy - sum(y*dy)) - dy*sum(g*y) )          (g_dy is softmax_bwd(y, g)). */
+int mssr_softmax_bwd_bwd(const void* g, const void* y, const void* dy, void* g_y, int64_t rows, int n,
+                         int64_t ld, float scale, int dtype, void* stream);
+
+/* --------------------------------------------------------------------- elementwise --------
+ * dropout / residual sites: onmt/encoders/transformer.py:51, onmt/decoders/transformer.py:
+ * 162,169, onmt/modules/position_ffn.py:35-37, multi_headed_attn.py:203, embeddings.py:53. */
+/* y = keep * x / (1-p) (+ residual); keep ~ Bernoulli(1-p) from a counter-based hash of
+ * (seed, element index); keep mask written to mask_out (uint8) for the backward passes. */
+int mssr_dropout_fwd(const void* x, const void* residual, void* y, uint8_t* mask_out, int64_t n,
+                     float p, uint64_t seed, int dtype, void* stream);
+/* y = x * mask * scale (+ residual): re-applies a stored keep mask (dropout backward / replay). */
+int mssr_mask_scale(const void* x, const uint8_t* mask, const void* residual, void* y, int64_t n,
+                    float scale, int dtype, void* stream);
+/* y = x * (gate > 0): ReLU backward as an op (position_ffn.py:35). */
+int mssr_gate_gt0(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream);
+/* out[n] (+)= sum over rows of x[rows, n] (Linear bias gradient). */
+int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int accumulate,
+                int dtype, void* stream);
+/* y = a*x + b*z elementwise (z may be NULL). */
+int mssr_axpby(const void* x, const void* z, void* y, int64_t n, float a, float b, int dtype,
+               void* stream);
+
+/* ---------------------------------------------------------------- embeddings + PE ---------
+ * Replaces nn.Embedding lookup + PositionalEncoding (onmt/modules/embeddings.py:48-54,282):
+ * out[r,:] = W[ids[r],:]*scale + pe[pos(r),:],  pos(r) = step >= 0 ? step : r / batch.
+ * W is float [V,d] (the parameter itself), pe is float [max_len, d]. */
+int mssr_embedding_fwd(const int64_t* ids, const float* weight, const float* pe, void* out,
+                       int64_t rows, int d, int64_t vocab, int64_t batch, int step, float scale,
+                       int dtype, void* stream);
+/* dW[ids[r],:] += scale * dout[r,:] for ids[r] != pad_idx (float atomics). */
+int mssr_embedding_bwd(const void* dout, const int64_t* ids, float* dweight, int64_t rows, int d,
+                       int64_t vocab, int64_t pad_idx, float scale, int dtype, void* stream);
+/* Soft path epilogue (embeddings.py:48-52 after :280): out = x*scale + pe[pos(r)]. */
+int mssr_scale_add_pe(const void* x, const float* pe, void* out, int64_t rows, int d, int64_t batch,
+                      int step, float scale, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MSSR_HIP_H */

@@ -1,0 +1,101 @@
+"""ctypes binding of libmssr_hip.so (include/mssr_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (hipcc, gfx950).  There is NO
+fallback: if the shared object is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int64, c_uint64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmssr_hip.so")
+
+F32, BF16 = 0, 1
+_DT = {torch.float32: F32, torch.bfloat16: BF16}
+
+
+class GemmDesc(Structure):
+    _fields_ = [("a", c_void_p), ("b", c_void_p), ("c", c_void_p), ("bias", c_void_p),
+                ("residual", c_void_p), ("gate", c_void_p),
+                ("m", c_int64), ("n", c_int64), ("k", c_int64),
+                ("a_rs", c_int64), ("a_cs", c_int64), ("b_rs", c_int64), ("b_cs", c_int64),
+                ("ldc", c_int64), ("ldr", c_int64), ("ldg", c_int64),
+                ("batch_outer", c_int64), ("batch_inner", c_int64),
+                ("a_bo", c_int64), ("a_bi", c_int64), ("b_bo", c_int64), ("b_bi", c_int64),
+                ("c_bo", c_int64), ("c_bi", c_int64),
+                ("alpha", c_float), ("beta", c_float), ("relu", c_int),
+                ("in_dtype", c_int), ("out_dtype", c_int)]
+
+
+_P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
+SIGNATURES = {
+    "mssr_abi_version": ([], c_int),
+    "mssr_last_error": ([], c_char_p),
+    "mssr_layernorm_fwd": ([_P, _P, _P, _P, _P, _P, _L, _I, _F, _I, _P], c_int),
+    "mssr_layernorm_partial_rows": ([_L], c_int),
+    "mssr_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
+    "mssr_layernorm_bwd_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
+    "mssr_gemm": ([POINTER(GemmDesc), _P], c_int),
+    "mssr_softmax_fwd": ([_P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _I, _P], c_int),
+    "mssr_softmax_bwd": ([_P, _P, _P, _L, _I, _L, _L, _L, _F, _I, _I, _I, _I, _P], c_int),
+    "mssr_softmax_bwd_bwd": ([_P, _P, _P, _P, _L, _I, _L, _F, _I, _P], c_int),
+    "mssr_dropout_fwd": ([_P, _P, _P, _P, _L, _F, _U, _I, _P], c_int),
+    "mssr_mask_scale": ([_P, _P, _P, _P, _L, _F, _I, _P], c_int),
+    "mssr_gate_gt0": ([_P, _P, _P, _L, _I, _P], c_int),
+    "mssr_colsum": ([_P, _P, _L, _I, _L, _I, _I, _P], c_int),
+    "mssr_axpby": ([_P, _P, _P, _L, _F, _F, _I, _P], c_int),
+    "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
+    "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
+    "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),
+}
+
+_lib = None
+
+
+def load():
+    """dlopen the library once and attach the C signatures.  Fails loudly if it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "mssrnet_style_transfer_amd: %s is missing -- build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (hipcc, gfx950). "
+            "There is no CPU or eager fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (argtypes, restype) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError here = ABI mismatch: also loud
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mssr_last_error().decode("utf-8", "replace")
+        raise RuntimeError("libmssr_hip %s failed (code %d): %s" % (what, rc, msg))
+
+
+def dt(t):
+    try:
+        return _DT[t.dtype]
+    except KeyError:
+        raise TypeError("unsupported dtype %s (need float32 or bfloat16)" % t.dtype)
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("mssrnet_style_transfer_amd kernels need tensors on the GPU (got %s); "
+                               "there is no CPU path" % t.device)

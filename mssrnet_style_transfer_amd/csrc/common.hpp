@@ -1,0 +1,92 @@
+// Shared device/host helpers for the gfx950 kernels of libmssr_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/mssr_hip.h"
+
+namespace mssr {
+
+void set_error(const char* fmt, ...);
+
+#define MSSR_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            ::mssr::set_error(__VA_ARGS__);     \
+            return MSSR_ERR_ARG;                \
+        }                                       \
+    } while (0)
+
+#define MSSR_LAUNCH_OK(name)                                                        \
+    do {                                                                            \
+        hipError_t e__ = hipGetLastError();                                         \
+        if (e__ != hipSuccess) {                                                    \
+            ::mssr::set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return MSSR_ERR_LAUNCH;                                                 \
+        }                                                                           \
+        return MSSR_OK;                                                             \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+typedef __bf16 bf16;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float to_f(float v) { return v; }
+__device__ __forceinline__ float to_f(bf16 v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16 from_f<bf16>(float v) { return (bf16)v; }
+
+// 4 consecutive elements <-> float[4]  (16-B access for f32, 8-B for bf16)
+template <typename T> struct V4;
+template <> struct V4<float> {
+    static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
+        float4 v = *reinterpret_cast<const float4*>(p);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct V4<bf16> {
+    static __device__ __forceinline__ void load(const bf16* p, float (&o)[4]) {
+        bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+        o[0] = (float)v[0]; o[1] = (float)v[1]; o[2] = (float)v[2]; o[3] = (float)v[3];
+    }
+    static __device__ __forceinline__ void store(bf16* p, const float (&o)[4]) {
+        bf16x4 v;
+        v[0] = (bf16)o[0]; v[1] = (bf16)o[1]; v[2] = (bf16)o[2]; v[3] = (bf16)o[3];
+        *reinterpret_cast<bf16x4*>(p) = v;
+    }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// counter-based RNG for dropout: one 32-bit hash per element index (splitmix-style finaliser)
+__device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
+    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (uint32_t)(z >> 32);
+}
+
+inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
+inline bool valid_dtype(int d) { return d == MSSR_F32 || d == MSSR_BF16; }
+inline size_t dsize(int d) { return d == MSSR_BF16 ? 2 : 4; }
+
+}  // namespace mssr

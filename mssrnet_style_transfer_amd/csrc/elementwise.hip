@@ -1,0 +1,312 @@
+// Elementwise / reduction helpers: dropout(+residual), mask replay, ReLU gate, column sums,
+// axpby, embedding lookup + positional encoding.  All HBM-bound streaming kernels:
+// 4 elements per lane per access (16 B for f32, 8 B for bf16), grid capped at 2048 blocks.
+#include "common.hpp"
+
+namespace mssr {
+
+constexpr int EW_BLOCK = 256;
+static inline unsigned ew_grid(int64_t nvec) {
+    int64_t b = (nvec + EW_BLOCK - 1) / EW_BLOCK;
+    if (b < 1) b = 1;
+    return (unsigned)(b < 2048 ? b : 2048);
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void dropout_fwd_kernel(const T* __restrict__ x, const T* __restrict__ res,
+                                                               T* __restrict__ y, uint8_t* __restrict__ mask,
+                                                               int64_t n, float p, uint64_t seed) {
+    const float inv = 1.0f / (1.0f - p);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < nv; i += stride) {
+        float v[4], r[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        V4<T>::load(x + i * 4, v);
+        if (res) V4<T>::load(res + i * 4, r);
+        uint32_t packed = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t keep = hash_u32(seed, (uint64_t)(i * 4 + j)) >= thr ? 1u : 0u;
+            packed |= keep << (8 * j);
+            o[j] = (keep ? v[j] * inv : 0.f) + r[j];
+        }
+        V4<T>::store(y + i * 4, o);
+        *reinterpret_cast<uint32_t*>(mask + i * 4) = packed;
+    }
+    // tail (n % 4)
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        const bool keep = hash_u32(seed, (uint64_t)i) >= thr;
+        mask[i] = keep ? 1 : 0;
+        y[i] = from_f<T>((keep ? to_f(x[i]) * inv : 0.f) + (res ? to_f(res[i]) : 0.f));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void mask_scale_kernel(const T* __restrict__ x, const uint8_t* __restrict__ mask,
+                                                              const T* __restrict__ res, T* __restrict__ y, int64_t n,
+                                                              float scale) {
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < nv; i += stride) {
+        float v[4], r[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        V4<T>::load(x + i * 4, v);
+        if (res) V4<T>::load(res + i * 4, r);
+        const uint32_t m = *reinterpret_cast<const uint32_t*>(mask + i * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = (((m >> (8 * j)) & 0xff) ? v[j] * scale : 0.f) + r[j];
+        V4<T>::store(y + i * 4, o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        y[i] = from_f<T>((mask[i] ? to_f(x[i]) * scale : 0.f) + (res ? to_f(res[i]) : 0.f));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void gate_kernel(const T* __restrict__ x, const T* __restrict__ gate,
+                                                        T* __restrict__ y, int64_t n) {
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < nv; i += stride) {
+        float v[4], g[4], o[4];
+        V4<T>::load(x + i * 4, v);
+        V4<T>::load(gate + i * 4, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = g[j] > 0.f ? v[j] : 0.f;
+        V4<T>::store(y + i * 4, o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        y[i] = from_f<T>(to_f(gate[i]) > 0.f ? to_f(x[i]) : 0.f);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(const T* __restrict__ x, const T* __restrict__ z,
+                                                         T* __restrict__ y, int64_t n, float a, float b) {
+    const int64_t nv = n >> 2;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < nv; i += stride) {
+        float v[4], w[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        V4<T>::load(x + i * 4, v);
+        if (z) V4<T>::load(z + i * 4, w);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = a * v[j] + b * w[j];
+        V4<T>::store(y + i * 4, o);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = (nv << 2) + threadIdx.x;
+        y[i] = from_f<T>(a * to_f(x[i]) + (z ? b * to_f(z[i]) : 0.f));
+    }
+}
+
+// Column sums: block (64 x 4): 64 consecutive columns x 4 row-lanes; rows split over gridDim.y,
+// partial results combined with float atomics (out zeroed by the host call unless accumulate).
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                     int n, int64_t ldx) {
+    __shared__ float sm[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (c < n) {
+        for (int64_t r = (int64_t)blockIdx.y * 4 + ty; r < rows; r += (int64_t)gridDim.y * 4)
+            s += to_f(x[r * ldx + c]);
+    }
+    sm[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < n) atomicAdd(out + c, (sm[0][tx] + sm[1][tx]) + (sm[2][tx] + sm[3][tx]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void embedding_fwd_kernel(const int64_t* __restrict__ ids,
+                                                                 const float* __restrict__ weight,
+                                                                 const float* __restrict__ pe, T* __restrict__ out,
+                                                                 int64_t rows, int d, int64_t vocab, int64_t batch,
+                                                                 int step, float scale) {
+    const int vper = d >> 2;
+    const int64_t total = rows * vper;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / vper;
+        const int c = (int)(i - r * vper) * 4;
+        int64_t id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        const int64_t pos = step >= 0 ? step : r / batch;
+        float w[4], p[4], o[4];
+        V4<float>::load(weight + id * d + c, w);
+        V4<float>::load(pe + pos * d + c, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = w[j] * scale + p[j];
+        V4<T>::store(out + r * d + c, o);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void embedding_bwd_kernel(const T* __restrict__ dout,
+                                                                 const int64_t* __restrict__ ids,
+                                                                 float* __restrict__ dweight, int64_t rows, int d,
+                                                                 int64_t vocab, int64_t pad_idx, float scale) {
+    const int64_t total = rows * d;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / d;
+        const int c = (int)(i - r * d);
+        const int64_t id = ids[r];
+        if (id == pad_idx || id < 0 || id >= vocab) continue;
+        atomicAdd(dweight + id * d + c, scale * to_f(dout[i]));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(EW_BLOCK) void scale_add_pe_kernel(const T* __restrict__ x, const float* __restrict__ pe,
+                                                                T* __restrict__ out, int64_t rows, int d, int64_t batch,
+                                                                int step, float scale) {
+    const int vper = d >> 2;
+    const int64_t total = rows * vper;
+    const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
+    for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < total; i += stride) {
+        const int64_t r = i / vper;
+        const int c = (int)(i - r * vper) * 4;
+        const int64_t pos = step >= 0 ? step : r / batch;
+        float v[4], p[4], o[4];
+        V4<T>::load(x + r * d + c, v);
+        V4<float>::load(pe + pos * d + c, p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j] * scale + p[j];
+        V4<T>::store(out + r * d + c, o);
+    }
+}
+
+}  // namespace mssr
+
+using namespace mssr;
+
+#define EW_COMMON(who)                                                          \
+    MSSR_REQUIRE(valid_dtype(dtype), who ": bad dtype %d", dtype);              \
+    MSSR_REQUIRE(n >= 0, who ": bad n");                                        \
+    if (n == 0) return MSSR_OK;                                                 \
+    hipStream_t s = (hipStream_t)stream;
+
+extern "C" int mssr_dropout_fwd(const void* x, const void* residual, void* y, uint8_t* mask_out, int64_t n, float p,
+                                uint64_t seed, int dtype, void* stream) {
+    EW_COMMON("dropout_fwd");
+    MSSR_REQUIRE(x && y && mask_out, "dropout_fwd: null pointer");
+    MSSR_REQUIRE(p >= 0.f && p < 1.f, "dropout_fwd: p=%f out of [0,1)", p);
+    MSSR_REQUIRE(aligned(x, 16) && aligned(y, 16) && aligned(mask_out, 4) && (!residual || aligned(residual, 16)),
+                 "dropout_fwd: misaligned pointer");
+    const unsigned g = ew_grid(n >> 2);
+    if (dtype == MSSR_F32)
+        dropout_fwd_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const float*)x, (const float*)residual, (float*)y, mask_out, n, p, seed);
+    else
+        dropout_fwd_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)x, (const bf16*)residual, (bf16*)y, mask_out, n, p, seed);
+    MSSR_LAUNCH_OK("dropout_fwd");
+}
+
+extern "C" int mssr_mask_scale(const void* x, const uint8_t* mask, const void* residual, void* y, int64_t n,
+                               float scale, int dtype, void* stream) {
+    EW_COMMON("mask_scale");
+    MSSR_REQUIRE(x && y && mask, "mask_scale: null pointer");
+    MSSR_REQUIRE(aligned(x, 16) && aligned(y, 16) && aligned(mask, 4) && (!residual || aligned(residual, 16)),
+                 "mask_scale: misaligned pointer");
+    const unsigned g = ew_grid(n >> 2);
+    if (dtype == MSSR_F32)
+        mask_scale_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const float*)x, mask, (const float*)residual, (float*)y, n, scale);
+    else
+        mask_scale_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)x, mask, (const bf16*)residual, (bf16*)y, n, scale);
+    MSSR_LAUNCH_OK("mask_scale");
+}
+
+extern "C" int mssr_gate_gt0(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream) {
+    EW_COMMON("gate_gt0");
+    MSSR_REQUIRE(x && y && gate, "gate_gt0: null pointer");
+    MSSR_REQUIRE(aligned(x, 16) && aligned(y, 16) && aligned(gate, 16), "gate_gt0: misaligned pointer");
+    const unsigned g = ew_grid(n >> 2);
+    if (dtype == MSSR_F32)
+        gate_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const float*)x, (const float*)gate, (float*)y, n);
+    else
+        gate_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)x, (const bf16*)gate, (bf16*)y, n);
+    MSSR_LAUNCH_OK("gate_gt0");
+}
+
+extern "C" int mssr_axpby(const void* x, const void* z, void* y, int64_t n, float a, float b, int dtype,
+                          void* stream) {
+    EW_COMMON("axpby");
+    MSSR_REQUIRE(x && y, "axpby: null pointer");
+    MSSR_REQUIRE(aligned(x, 16) && aligned(y, 16) && (!z || aligned(z, 16)), "axpby: misaligned pointer");
+    const unsigned g = ew_grid(n >> 2);
+    if (dtype == MSSR_F32)
+        axpby_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const float*)x, (const float*)z, (float*)y, n, a, b);
+    else
+        axpby_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)x, (const bf16*)z, (bf16*)y, n, a, b);
+    MSSR_LAUNCH_OK("axpby");
+}
+
+extern "C" int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int accumulate, int dtype,
+                           void* stream) {
+    MSSR_REQUIRE(valid_dtype(dtype), "colsum: bad dtype %d", dtype);
+    MSSR_REQUIRE(rows >= 0 && n > 0 && ldx >= n, "colsum: bad shape rows=%lld n=%d ldx=%lld", (long long)rows, n,
+                 (long long)ldx);
+    MSSR_REQUIRE(out && (x || rows == 0), "colsum: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n, s);
+    if (rows == 0) return MSSR_OK;
+    int64_t gy = (rows + 63) / 64;
+    if (gy > 64) gy = 64;
+    const dim3 grid((n + 63) / 64, (unsigned)gy);
+    if (dtype == MSSR_F32)
+        colsum_kernel<float><<<grid, dim3(256), 0, s>>>((const float*)x, out, rows, n, ldx);
+    else
+        colsum_kernel<bf16><<<grid, dim3(256), 0, s>>>((const bf16*)x, out, rows, n, ldx);
+    MSSR_LAUNCH_OK("colsum");
+}
+
+extern "C" int mssr_embedding_fwd(const int64_t* ids, const float* weight, const float* pe, void* out, int64_t rows,
+                                  int d, int64_t vocab, int64_t batch, int step, float scale, int dtype,
+                                  void* stream) {
+    MSSR_REQUIRE(valid_dtype(dtype), "embedding_fwd: bad dtype %d", dtype);
+    MSSR_REQUIRE(rows >= 0 && d > 0 && d % 4 == 0 && vocab > 0 && batch > 0, "embedding_fwd: bad shape");
+    if (rows == 0) return MSSR_OK;
+    MSSR_REQUIRE(ids && weight && pe && out, "embedding_fwd: null pointer");
+    MSSR_REQUIRE(aligned(weight, 16) && aligned(pe, 16) && aligned(out, 16), "embedding_fwd: misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = ew_grid(rows * (d >> 2));
+    if (dtype == MSSR_F32)
+        embedding_fwd_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>(ids, weight, pe, (float*)out, rows, d, vocab, batch, step, scale);
+    else
+        embedding_fwd_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>(ids, weight, pe, (bf16*)out, rows, d, vocab, batch, step, scale);
+    MSSR_LAUNCH_OK("embedding_fwd");
+}
+
+extern "C" int mssr_embedding_bwd(const void* dout, const int64_t* ids, float* dweight, int64_t rows, int d,
+                                  int64_t vocab, int64_t pad_idx, float scale, int dtype, void* stream) {
+    MSSR_REQUIRE(valid_dtype(dtype), "embedding_bwd: bad dtype %d", dtype);
+    MSSR_REQUIRE(rows >= 0 && d > 0 && vocab > 0, "embedding_bwd: bad shape");
+    if (rows == 0) return MSSR_OK;
+    MSSR_REQUIRE(ids && dweight && dout, "embedding_bwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = ew_grid(rows * d);
+    if (dtype == MSSR_F32)
+        embedding_bwd_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const float*)dout, ids, dweight, rows, d, vocab, pad_idx, scale);
+    else
+        embedding_bwd_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)dout, ids, dweight, rows, d, vocab, pad_idx, scale);
+    MSSR_LAUNCH_OK("embedding_bwd");
+}
+
+extern "C" int mssr_scale_add_pe(const void* x, const float* pe, void* out, int64_t rows, int d, int64_t batch,
+                                 int step, float scale, int dtype, void* stream) {
+    MSSR_REQUIRE(valid_dtype(dtype), "scale_add_pe: bad dtype %d", dtype);
+    MSSR_REQUIRE(rows >= 0 && d > 0 && d % 4 == 0 && batch > 0, "scale_add_pe: bad shape");
+    if (rows == 0) return MSSR_OK;
+    MSSR_REQUIRE(x && pe && out, "scale_add_pe: null pointer");
+    MSSR_REQUIRE(aligned(x, 16) && aligned(pe, 16) && aligned(out, 16), "scale_add_pe: misaligned pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const unsigned g = ew_grid(rows * (d >> 2));
+    if (dtype == MSSR_F32)
+        scale_add_pe_kernel<float><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const float*)x, pe, (float*)out, rows, d, batch, step, scale);
+    else
+        scale_add_pe_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)x, pe, (bf16*)out, rows, d, batch, step, scale);
+    MSSR_LAUNCH_OK("scale_add_pe");
+}

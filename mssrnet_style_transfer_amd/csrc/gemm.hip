@@ -1,0 +1,243 @@
+// Strided-batched GEMM with fused epilogue on the gfx950 matrix cores.
+//   bf16 inputs: v_mfma_f32_16x16x32_bf16     f32 inputs: v_mfma_f32_16x16x4_f32 (exact f32)
+// Block = 256 threads = 4 waves (2 x 2); block tile BM x BN (64x64 or 32x32), BK = 32.
+// Both operands are staged through LDS as [row][k] images (k contiguous, rows padded by 16 B)
+// so one fragment is one 16-B LDS read (bf16) regardless of the operand's layout in HBM;
+// the next K-tile is fetched into registers while the current one feeds the MFMAs.
+// Operands may be k-contiguous ("NT" weights, activations) or row-contiguous (transposed
+// views: dW = dY^T X, P V, ...): the loader picks the coalesced direction per operand.
+#include "common.hpp"
+
+namespace mssr {
+
+constexpr int GEMM_THREADS = 256;
+constexpr int BK = 32;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16> {
+    static constexpr int KSTEP = 32;
+    static constexpr int PAD = 8;   // elements: +16 B per row
+    typedef bf16x8 Frag;
+    static __device__ __forceinline__ Frag load(const bf16* row, int kk, int lane) {
+        return *reinterpret_cast<const bf16x8*>(row + kk * KSTEP + 8 * (lane >> 4));
+    }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static constexpr int KSTEP = 4;
+    static constexpr int PAD = 4;   // +16 B per row
+    typedef float Frag;
+    static __device__ __forceinline__ Frag load(const float* row, int kk, int lane) {
+        return row[kk * KSTEP + (lane >> 4)];
+    }
+    static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
+        return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+    }
+};
+
+struct GemmArgs {
+    const void* a;
+    const void* b;
+    void* c;
+    const float* bias;
+    const void* residual;
+    const void* gate;
+    int64_t m, n, k;
+    int64_t a_rs, a_cs, b_rs, b_cs, ldc, ldr, ldg;
+    int64_t batch_inner;
+    int64_t a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;
+    float alpha, beta;
+    int relu;
+    int a_vec, b_vec;   // 16-B vector loads allowed for this operand
+};
+
+// One operand tile [ROWS][BK] of a matrix addressed as elem(r, k) = src[r*rs + k*cs].
+// Each thread owns NCH chunks of CH = 16 B / sizeof(T) elements.
+template <typename T, int ROWS>
+struct TileLoader {
+    static constexpr int CH = 16 / sizeof(T);
+    static constexpr int CHUNKS = ROWS * BK / CH;
+    static constexpr int NCH = (CHUNKS + GEMM_THREADS - 1) / GEMM_THREADS;
+    static constexpr int LD = BK + Mma<T>::PAD;
+    T reg[NCH][CH];
+
+    // kmajor: k is the contiguous direction (cs == 1); else rows are contiguous (rs == 1)
+    __device__ __forceinline__ void fetch(const T* __restrict__ src, int64_t row0, int64_t k0, int64_t nrows,
+                                          int64_t K, int64_t rs, int64_t cs, bool kmajor, bool vec) {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int idx = c * GEMM_THREADS + threadIdx.x;
+            if (CHUNKS % GEMM_THREADS != 0 && idx >= CHUNKS) break;
+            int r, kk;
+            if (kmajor) {
+                r = idx / (BK / CH);
+                kk = (idx % (BK / CH)) * CH;
+            } else {
+                kk = idx / (ROWS / CH);
+                r = (idx % (ROWS / CH)) * CH;
+            }
+            const int64_t gr = row0 + r, gk = k0 + kk;
+            const T* p = src + gr * rs + gk * cs;
+            const bool full = kmajor ? (gr < nrows && gk + CH <= K) : (gk < K && gr + CH <= nrows);
+            if (vec && full) {
+                *reinterpret_cast<uint4*>(&reg[c][0]) = *reinterpret_cast<const uint4*>(p);
+            } else {
+#pragma unroll
+                for (int j = 0; j < CH; ++j) {
+                    const bool ok = kmajor ? (gr < nrows && gk + j < K) : (gk < K && gr + j < nrows);
+                    reg[c][j] = ok ? p[kmajor ? j * cs : j * rs] : from_f<T>(0.f);
+                }
+            }
+        }
+    }
+    __device__ __forceinline__ void commit(T* __restrict__ lds, bool kmajor) const {
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int idx = c * GEMM_THREADS + threadIdx.x;
+            if (CHUNKS % GEMM_THREADS != 0 && idx >= CHUNKS) break;
+            if (kmajor) {
+                const int r = idx / (BK / CH), kk = (idx % (BK / CH)) * CH;
+                *reinterpret_cast<uint4*>(lds + r * LD + kk) = *reinterpret_cast<const uint4*>(&reg[c][0]);
+            } else {
+                const int kk = idx / (ROWS / CH), r = (idx % (ROWS / CH)) * CH;
+#pragma unroll
+                for (int j = 0; j < CH; ++j) lds[(r + j) * LD + kk] = reg[c][j];
+            }
+        }
+    }
+};
+
+template <typename TI, typename TO, int BM, int BN>
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
+    constexpr int LD = BK + Mma<TI>::PAD;
+    constexpr int WM = BM / 2, WN = BN / 2;        // wave tile
+    constexpr int FM = WM / 16, FN = WN / 16;      // 16x16 fragments per wave
+    __shared__ __attribute__((aligned(16))) TI As[BM * LD];
+    __shared__ __attribute__((aligned(16))) TI Bs[BN * LD];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int64_t zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+    const TI* A = reinterpret_cast<const TI*>(p.a) + zo * p.a_bo + zi * p.a_bi;
+    const TI* B = reinterpret_cast<const TI*>(p.b) + zo * p.b_bo + zi * p.b_bi;
+    const int64_t coff = zo * p.c_bo + zi * p.c_bi;
+    const int64_t m0 = (int64_t)blockIdx.y * BM, n0 = (int64_t)blockIdx.x * BN;
+    const bool a_km = p.a_cs == 1, b_km = p.b_rs == 1;   // B viewed [k,n]: k contiguous when b_rs == 1
+
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    TileLoader<TI, BM> la;
+    TileLoader<TI, BN> lb;
+    const int64_t nk = (p.k + BK - 1) / BK;
+    la.fetch(A, m0, 0, p.m, p.k, p.a_rs, p.a_cs, a_km, p.a_vec);
+    lb.fetch(B, n0, 0, p.n, p.k, p.b_cs, p.b_rs, b_km, p.b_vec);   // rows of the B image are n
+    for (int64_t t = 0; t < nk; ++t) {
+        la.commit(As, a_km);
+        lb.commit(Bs, b_km);
+        __syncthreads();
+        if (t + 1 < nk) {
+            la.fetch(A, m0, (t + 1) * BK, p.m, p.k, p.a_rs, p.a_cs, a_km, p.a_vec);
+            lb.fetch(B, n0, (t + 1) * BK, p.n, p.k, p.b_cs, p.b_rs, b_km, p.b_vec);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / Mma<TI>::KSTEP; ++kk) {
+            typename Mma<TI>::Frag fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = Mma<TI>::load(As + (wm * WM + i * 16 + (lane & 15)) * LD, kk, lane);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = Mma<TI>::load(Bs + (wn * WN + j * 16 + (lane & 15)) * LD, kk, lane);
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = Mma<TI>::mma(fa[i], fb[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 16x16 MFMA: col = lane & 15, row = (lane >> 4)*4 + reg
+    TO* C = reinterpret_cast<TO*>(p.c) + coff;
+    const TI* R = p.residual ? reinterpret_cast<const TI*>(p.residual) + coff : nullptr;
+    const TI* G = p.gate ? reinterpret_cast<const TI*>(p.gate) + coff : nullptr;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int64_t col = n0 + wn * WN + j * 16 + (lane & 15);
+            if (col >= p.n) continue;
+            const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int64_t row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
+                if (row >= p.m) continue;
+                float v = p.alpha * acc[i][j][r] + bias;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (R) v += to_f(R[row * p.ldr + col]);
+                if (G) v = to_f(G[row * p.ldg + col]) > 0.f ? v : 0.f;
+                if (p.beta != 0.f) v += p.beta * to_f(C[row * p.ldc + col]);
+                C[row * p.ldc + col] = from_f<TO>(v);
+            }
+        }
+    }
+}
+
+template <typename TI, typename TO>
+static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
+    const int64_t tiles64 = ((a.m + 63) / 64) * ((a.n + 63) / 64) * batch;
+    if (tiles64 >= 192 && a.m > 32 && a.n > 32) {
+        dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 63) / 64), (unsigned)batch);
+        gemm_kernel<TI, TO, 64, 64><<<grid, dim3(GEMM_THREADS), 0, s>>>(a);
+    } else {
+        dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)batch);
+        gemm_kernel<TI, TO, 32, 32><<<grid, dim3(GEMM_THREADS), 0, s>>>(a);
+    }
+}
+
+}  // namespace mssr
+
+using namespace mssr;
+
+extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
+    MSSR_REQUIRE(d, "gemm: null descriptor");
+    MSSR_REQUIRE(valid_dtype(d->in_dtype) && valid_dtype(d->out_dtype), "gemm: bad dtype");
+    MSSR_REQUIRE(!(d->in_dtype == MSSR_F32 && d->out_dtype == MSSR_BF16), "gemm: f32 -> bf16 is not supported");
+    MSSR_REQUIRE(d->m >= 0 && d->n >= 0 && d->k >= 0, "gemm: negative size");
+    MSSR_REQUIRE(d->batch_outer >= 1 && d->batch_inner >= 1, "gemm: batch counts must be >= 1");
+    const int64_t batch = d->batch_outer * d->batch_inner;
+    MSSR_REQUIRE(batch <= 65535, "gemm: batch %lld exceeds 65535", (long long)batch);
+    if (d->m == 0 || d->n == 0) return MSSR_OK;
+    MSSR_REQUIRE(d->a && d->b && d->c, "gemm: null pointer");
+    MSSR_REQUIRE(d->a_rs == 1 || d->a_cs == 1, "gemm: A needs a unit stride (a_rs=%lld a_cs=%lld)",
+                 (long long)d->a_rs, (long long)d->a_cs);
+    MSSR_REQUIRE(d->b_rs == 1 || d->b_cs == 1, "gemm: B needs a unit stride (b_rs=%lld b_cs=%lld)",
+                 (long long)d->b_rs, (long long)d->b_cs);
+    MSSR_REQUIRE(d->ldc >= d->n, "gemm: ldc < n");
+    MSSR_REQUIRE(!d->residual || d->ldr >= d->n, "gemm: ldr < n");
+    MSSR_REQUIRE(!d->gate || d->ldg >= d->n, "gemm: ldg < n");
+    MSSR_REQUIRE((d->m + 31) / 32 <= 65535, "gemm: m too large");
+
+    GemmArgs a;
+    a.a = d->a; a.b = d->b; a.c = d->c; a.bias = d->bias; a.residual = d->residual; a.gate = d->gate;
+    a.m = d->m; a.n = d->n; a.k = d->k;
+    a.a_rs = d->a_rs; a.a_cs = d->a_cs; a.b_rs = d->b_rs; a.b_cs = d->b_cs;
+    a.ldc = d->ldc; a.ldr = d->ldr; a.ldg = d->ldg;
+    a.batch_inner = d->batch_inner;
+    a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
+    a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
+    const int ch = 16 / (int)dsize(d->in_dtype);
+    // 16-B vector loads need: base aligned, the non-unit stride and batch strides multiples of the chunk
+    const int64_t a_ld = d->a_cs == 1 ? d->a_rs : d->a_cs;
+    const int64_t b_ld = d->b_rs == 1 ? d->b_cs : d->b_rs;
+    a.a_vec = aligned(d->a, 16) && a_ld % ch == 0 && d->a_bo % ch == 0 && d->a_bi % ch == 0;
+    a.b_vec = aligned(d->b, 16) && b_ld % ch == 0 && d->b_bo % ch == 0 && d->b_bi % ch == 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->in_dtype == MSSR_F32) launch<float, float>(a, batch, s);
+    else if (d->out_dtype == MSSR_BF16) launch<bf16, bf16>(a, batch, s);
+    else launch<bf16, float>(a, batch, s);
+    MSSR_LAUNCH_OK("gemm");
+}

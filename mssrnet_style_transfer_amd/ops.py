@@ -1,0 +1,558 @@
+"""Differentiable operators over the C-ABI kernels (include/mssr_hip.h).
+
+Every operator is a ``torch.autograd.Function`` whose backward is itself built from these
+operators, so gradients of gradients exist wherever the WGAN-GP critics need them
+(``autograd.grad(..., create_graph=True)``, onmt/trainer_wgan_wh.py:1247-1250,1315-1318):
+matmul and the masked/gated elementwise ops are closed under differentiation; LayerNorm and
+softmax carry hand-written second-order kernels.  torch is used for memory, views and
+autograd book-keeping only; all arithmetic on activations runs in libmssr_hip.so.
+"""
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+
+_state = {"dtype": torch.float32, "seed_counter": 0}
+
+
+def set_compute_dtype(dtype):
+    """Activation / MFMA input type: torch.float32 (parity mode) or torch.bfloat16."""
+    if dtype not in (torch.float32, torch.bfloat16):
+        raise ValueError("compute dtype must be float32 or bfloat16")
+    _state["dtype"] = dtype
+    _cast_cache.clear()
+
+
+def compute_dtype():
+    return _state["dtype"]
+
+
+def next_seed():
+    """64-bit dropout seed: torch's initial seed mixed with a per-process call counter."""
+    _state["seed_counter"] += 1
+    return (torch.initial_seed() * 0x9E3779B97F4A7C15 + _state["seed_counter"] * 0xD1B54A32D192ED03) % (1 << 64)
+
+
+_cast_cache = {}
+
+
+def cast(t):
+    """Tensor in the compute dtype; casts of parameters are cached until the parameter changes."""
+    cd = _state["dtype"]
+    if t.dtype == cd:
+        return t
+    if t.is_leaf and t.dim() >= 2:
+        key = id(t)
+        hit = _cast_cache.get(key)
+        if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
+            return hit[2]
+        c = t.detach().to(cd)
+        _cast_cache[key] = (t._version, t.data_ptr(), c)
+        return c
+    return t.detach().to(cd) if not torch.is_grad_enabled() else t.to(cd)
+
+
+def _f32(t):
+    return t if t.dtype == torch.float32 else t.float()
+
+
+def _mat(t):
+    """(row stride, col stride) of the last two dims with one of them 1, copying if needed."""
+    r, c = t.shape[-2], t.shape[-1]
+    sr, sc = t.stride(-2), t.stride(-1)
+    if sc == 1 or c == 1:
+        return t, (sr if r > 1 else max(c, 1)), 1
+    if sr == 1 or r == 1:
+        return t, 1, sc
+    t = t.contiguous()
+    return t, t.stride(-2), 1
+
+
+def _batch(t):
+    """Leading dims as (outer, inner) sizes and strides (at most two batch dims)."""
+    nb = t.dim() - 2
+    if nb == 0:
+        return (1, 1), (0, 0)
+    if nb == 1:
+        return (1, t.shape[0]), (0, t.stride(0) if t.shape[0] > 1 else 0)
+    if nb == 2:
+        return (t.shape[0], t.shape[1]), (t.stride(0) if t.shape[0] > 1 else 0,
+                                          t.stride(1) if t.shape[1] > 1 else 0)
+    raise ValueError("matmul supports at most two batch dimensions")
+
+
+def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, alpha=1.0, out=None, beta=0.0):
+    """out[..., M, N] = epilogue(alpha * a[..., M, K] @ (b[..., N, K]^T if tb else b[..., K, N]))."""
+    L.require_cuda(a, b)
+    a, a_rs, a_cs = _mat(a)
+    b, s0, s1 = _mat(b)
+    if tb:                      # b is [.., N, K]; as [k, n]: k stride = s1, n stride = s0
+        n, k2 = b.shape[-2], b.shape[-1]
+        b_rs, b_cs = s1, s0
+    else:
+        k2, n = b.shape[-2], b.shape[-1]
+        b_rs, b_cs = s0, s1
+    m, k = a.shape[-2], a.shape[-1]
+    if k != k2:
+        raise ValueError("matmul: inner sizes differ (%d vs %d)" % (k, k2))
+    (bo, bi), (a_bo, a_bi) = _batch(a)
+    (bo2, bi2), (b_bo, b_bi) = _batch(b)
+    if (bo, bi) != (bo2, bi2):
+        raise ValueError("matmul: batch dims differ %s vs %s" % (a.shape, b.shape))
+    if a.dtype != b.dtype:
+        raise TypeError("matmul: operand dtypes differ (%s, %s)" % (a.dtype, b.dtype))
+    if out is None:
+        out = torch.empty(a.shape[:-2] + (m, n), dtype=out_dtype, device=a.device)
+    d = L.GemmDesc()
+    d.a, d.b, d.c = a.data_ptr(), b.data_ptr(), out.data_ptr()
+    d.bias = L.ptr(bias)
+    d.residual = L.ptr(residual)
+    d.gate = L.ptr(gate)
+    d.m, d.n, d.k = m, n, k
+    d.a_rs, d.a_cs, d.b_rs, d.b_cs = a_rs, a_cs, b_rs, b_cs
+    d.ldc = out.stride(-2) if m > 1 else max(n, 1)
+    d.ldr = residual.stride(-2) if residual is not None and m > 1 else n
+    d.ldg = gate.stride(-2) if gate is not None and m > 1 else n
+    d.batch_outer, d.batch_inner = bo, bi
+    d.a_bo, d.a_bi, d.b_bo, d.b_bi = a_bo, a_bi, b_bo, b_bi
+    (_, _), (d.c_bo, d.c_bi) = _batch(out)
+    d.alpha, d.beta, d.relu = alpha, beta, int(relu)
+    d.in_dtype, d.out_dtype = L.dt(a), L.dt(out)
+    L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
+    return out
+
+
+class _Matmul(Function):
+    """C = A @ B (tb=False, B [.., K, N]) or A @ B^T (tb=True, B [.., N, K]); closed under autograd."""
+
+    @staticmethod
+    def forward(ctx, a, b, tb, out_dtype, heads_last=False):
+        ctx.save_for_backward(a, b)
+        ctx.tb = tb
+        ac, bc = cast(a), cast(b)
+        out = None
+        if heads_last:          # [B,H,M,N] result stored as [B,M,H,N] (the "unshape" layout, mha.py:126-129)
+            B, H, M = ac.shape[0], ac.shape[1], ac.shape[2]
+            N = bc.shape[-2] if tb else bc.shape[-1]
+            out = torch.empty(B, M, H, N, dtype=out_dtype or _state["dtype"], device=ac.device).permute(0, 2, 1, 3)
+        return gemm(ac, bc, tb, out_dtype or _state["dtype"], out=out)
+
+    @staticmethod
+    def backward(ctx, dc):
+        a, b = ctx.saved_tensors
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = _Matmul.apply(dc, b, not ctx.tb, a.dtype)
+        if ctx.needs_input_grad[1]:
+            if ctx.tb:
+                db = _Matmul.apply(dc.transpose(-1, -2), a, False, b.dtype)
+            else:
+                db = _Matmul.apply(a.transpose(-1, -2), dc, False, b.dtype)
+        return da, db, None, None, None
+
+
+def matmul(a, b, tb=False, out_dtype=None, heads_last=False):
+    return _Matmul.apply(a, b, tb, out_dtype, heads_last)
+
+
+class _Gate(Function):
+    """x * (gate > 0)."""
+
+    @staticmethod
+    def forward(ctx, x, gate):
+        x = cast(x).contiguous()
+        gate = cast(gate).contiguous()
+        ctx.save_for_backward(gate)
+        y = torch.empty_like(x)
+        L.check(L.load().mssr_gate_gt0(x.data_ptr(), gate.data_ptr(), y.data_ptr(), x.numel(), L.dt(x), L.stream()),
+                "gate_gt0")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gate, = ctx.saved_tensors
+        return _Gate.apply(g, gate), None
+
+
+class _Colsum(Function):
+    """fp32 column sums of a [rows, n] matrix (Linear bias gradient)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = cast(x)
+        x2 = x.reshape(-1, x.shape[-1])
+        if x2.stride(-1) != 1:
+            x2 = x2.contiguous()
+        ctx.shape, ctx.dtype = x.shape, x.dtype
+        out = torch.empty(x2.shape[1], dtype=torch.float32, device=x.device)
+        L.check(L.load().mssr_colsum(x2.data_ptr(), out.data_ptr(), x2.shape[0], x2.shape[1],
+                                     x2.stride(0) if x2.shape[0] > 1 else x2.shape[1], 0, L.dt(x2), L.stream()),
+                "colsum")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(ctx.dtype).expand(ctx.shape)
+
+
+class _Linear(Function):
+    """y = [relu](x W^T + b) [+ residual] with the bias / ReLU / residual fused into the GEMM
+    epilogue (nn.Linear sites of the path; FFN position_ffn.py:35-37)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu, residual):
+        xc = cast(x)
+        if xc.stride(-1) != 1:
+            xc = xc.contiguous()
+        x2 = xc.reshape(-1, xc.shape[-1])
+        n = weight.shape[0]
+        res2 = None
+        if residual is not None:
+            res2 = cast(residual).reshape(-1, n)
+            if res2.stride(-1) != 1:
+                res2 = res2.contiguous()
+        y = gemm(x2, cast(weight), True, _state["dtype"], bias=None if bias is None else _f32(bias.detach()),
+                 relu=relu, residual=res2)
+        y = y.view(xc.shape[:-1] + (n,))
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x, weight, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dz = _Gate.apply(dy, y) if ctx.relu else dy
+        dz2 = dz.reshape(-1, dz.shape[-1])
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = _Matmul.apply(dz2, weight, False, x.dtype).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            dw = _Matmul.apply(dz2.transpose(0, 1), x.reshape(-1, x.shape[-1]), False, weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = _Colsum.apply(dz2)
+        dres = dy if ctx.has_res and ctx.needs_input_grad[4] else None
+        return dx, dw, db, None, dres
+
+
+def linear(x, weight, bias=None, relu=False, residual=None):
+    return _Linear.apply(x, weight, bias, relu, residual)
+
+
+class _LayerNorm(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = cast(x).contiguous()
+        L.require_cuda(xc, gamma, beta)
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        g32, b32 = _f32(gamma.detach()).contiguous(), _f32(beta.detach()).contiguous()
+        y = torch.empty_like(xc)
+        mean = torch.empty(rows, dtype=torch.float32, device=xc.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=xc.device)
+        L.check(L.load().mssr_layernorm_fwd(xc.data_ptr(), g32.data_ptr(), b32.data_ptr(), y.data_ptr(),
+                                            mean.data_ptr(), rstd.data_ptr(), rows, d, eps, L.dt(xc), L.stream()),
+                "layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = _LayerNormBwd.apply(dy, x, gamma, mean, rstd)
+        return dx, dg, db, None
+
+
+class _LayerNormBwd(Function):
+    @staticmethod
+    def forward(ctx, dy, x, gamma, mean, rstd):
+        xc, dyc = cast(x).contiguous(), cast(dy).contiguous()
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        lib = L.load()
+        g32 = _f32(gamma.detach()).contiguous()
+        dx = torch.empty_like(xc)
+        dg = torch.empty(d, dtype=torch.float32, device=xc.device)
+        db = torch.empty(d, dtype=torch.float32, device=xc.device)
+        parts = lib.mssr_layernorm_partial_rows(rows)
+        ws = torch.empty(2 * parts * d, dtype=torch.float32, device=xc.device)
+        L.check(lib.mssr_layernorm_bwd(dyc.data_ptr(), xc.data_ptr(), g32.data_ptr(), mean.data_ptr(),
+                                       rstd.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), ws.data_ptr(),
+                                       rows, d, L.dt(xc), L.stream()), "layernorm_bwd")
+        ctx.save_for_backward(dy, x, gamma, mean, rstd)
+        if dx.dtype != x.dtype:
+            dx = dx.to(x.dtype)
+        return dx, dg.to(gamma.dtype), db.to(gamma.dtype)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ggx, ggg, ggb):
+        dy, x, gamma, mean, rstd = ctx.saved_tensors
+        xc, dyc = cast(x).contiguous(), cast(dy).contiguous()
+        d = xc.shape[-1]
+        rows = xc.numel() // d
+        lib = L.load()
+        g32 = _f32(gamma.detach()).contiguous()
+        u = None if ggx is None else cast(ggx).contiguous()
+        vg = None if ggg is None else _f32(ggg).contiguous()
+        vb = None if ggb is None else _f32(ggb).contiguous()
+        g_dy = torch.empty_like(xc)
+        g_x = torch.empty_like(xc)
+        g_gamma = torch.empty(d, dtype=torch.float32, device=xc.device)
+        parts = lib.mssr_layernorm_partial_rows(rows)
+        ws = torch.empty(parts * d, dtype=torch.float32, device=xc.device)
+        L.check(lib.mssr_layernorm_bwd_bwd(L.ptr(u), L.ptr(vg), L.ptr(vb), dyc.data_ptr(), xc.data_ptr(),
+                                           g32.data_ptr(), mean.data_ptr(), rstd.data_ptr(), g_dy.data_ptr(),
+                                           g_x.data_ptr(), g_gamma.data_ptr(), ws.data_ptr(), rows, d, L.dt(xc),
+                                           L.stream()), "layernorm_bwd_bwd")
+        return g_dy.to(dy.dtype), g_x.to(x.dtype), g_gamma.to(gamma.dtype), None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-6):
+    return _LayerNorm.apply(x, gamma, beta, eps)
+
+
+def _mask_args(mask, x):
+    """uint8 view + (rows_per_batch, q_len, batch stride, query stride) of an attention mask
+    [B,1,Lk] / [B,Lq,Lk] applied to scores x [B,H,Lq,Lk]."""
+    if mask is None:
+        return None, 1, 1, 0, 0
+    m = mask if mask.stride(-1) == 1 else mask.contiguous()
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    elif m.dtype != torch.uint8:
+        m = (m != 0).view(torch.uint8)
+    B, H, Lq, Lk = x.shape
+    if m.dim() != 3 or m.shape[0] != B or m.shape[2] != Lk or m.shape[1] not in (1, Lq):
+        raise ValueError("mask shape %s does not fit scores %s" % (tuple(mask.shape), tuple(x.shape)))
+    return m, H * Lq, Lq, (m.stride(0) if B > 1 else 0), (m.stride(1) if m.shape[1] > 1 else 0)
+
+
+class _Softmax(Function):
+    """softmax / log_softmax(scale * x) along the last axis with optional attention mask."""
+
+    @staticmethod
+    def forward(ctx, x, mask, scale, log_mode, out_dtype):
+        xc = cast(x).contiguous()
+        L.require_cuda(xc)
+        n = xc.shape[-1]
+        rows = xc.numel() // n
+        m, rpb, ql, mbs, mqs = _mask_args(mask, xc) if mask is not None else (None, 1, 1, 0, 0)
+        y = torch.empty(xc.shape, dtype=out_dtype or xc.dtype, device=xc.device)
+        L.check(L.load().mssr_softmax_fwd(xc.data_ptr(), y.data_ptr(), L.ptr(m), rows, n, n, n, rpb, ql, mbs, mqs,
+                                          scale, int(log_mode), L.dt(xc), L.dt(y), L.stream()), "softmax_fwd")
+        ctx.save_for_backward(y)
+        ctx.scale, ctx.log_mode, ctx.in_dtype = scale, log_mode, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, = ctx.saved_tensors
+        return _SoftmaxBwd.apply(y, dy, ctx.scale, ctx.log_mode, ctx.in_dtype), None, None, None, None
+
+
+class _SoftmaxBwd(Function):
+    @staticmethod
+    def forward(ctx, y, dy, scale, log_mode, dx_dtype):
+        yc, dyc = y.contiguous(), dy.contiguous()
+        n = yc.shape[-1]
+        rows = yc.numel() // n
+        dx = torch.empty(yc.shape, dtype=dx_dtype, device=yc.device)
+        L.check(L.load().mssr_softmax_bwd(yc.data_ptr(), dyc.data_ptr(), dx.data_ptr(), rows, n, n, n, n, scale,
+                                          int(log_mode), L.dt(yc), L.dt(dyc), L.dt(dx), L.stream()), "softmax_bwd")
+        ctx.save_for_backward(y, dy)
+        ctx.scale, ctx.log_mode = scale, log_mode
+        return dx
+
+    @staticmethod
+    def backward(ctx, g):
+        y, dy = ctx.saved_tensors
+        if ctx.log_mode:
+            raise NotImplementedError("double backward of log_softmax is not on the MSSRNet path")
+        g_y = g_dy = None
+        if ctx.needs_input_grad[0]:
+            gc = g.to(y.dtype).contiguous()
+            dyc = dy.to(y.dtype).contiguous()
+            yc = y.contiguous()
+            n = yc.shape[-1]
+            g_y = torch.empty_like(yc)
+            L.check(L.load().mssr_softmax_bwd_bwd(gc.data_ptr(), yc.data_ptr(), dyc.data_ptr(), g_y.data_ptr(),
+                                                  yc.numel() // n, n, n, ctx.scale, L.dt(yc), L.stream()),
+                    "softmax_bwd_bwd")
+        if ctx.needs_input_grad[1]:
+            g_dy = _SoftmaxBwd.apply(y, g, ctx.scale, ctx.log_mode, dy.dtype)
+        return g_y, g_dy, None, None, None
+
+
+def softmax(x, mask=None, scale=1.0, out_dtype=None):
+    return _Softmax.apply(x, mask, scale, False, out_dtype)
+
+
+def log_softmax(x, scale=1.0, out_dtype=None):
+    return _Softmax.apply(x, None, scale, True, out_dtype)
+
+
+class _MaskScale(Function):
+    """y = x * keep * scale: the linear map dropout applies once its keep mask is fixed."""
+
+    @staticmethod
+    def forward(ctx, x, keep, scale):
+        xc = cast(x).contiguous()
+        y = torch.empty_like(xc)
+        L.check(L.load().mssr_mask_scale(xc.data_ptr(), keep.data_ptr(), None, y.data_ptr(), xc.numel(), scale,
+                                         L.dt(xc), L.stream()), "mask_scale")
+        ctx.save_for_backward(keep)
+        ctx.scale, ctx.dtype = scale, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        keep, = ctx.saved_tensors
+        return _MaskScale.apply(g, keep, ctx.scale).to(ctx.dtype), None, None
+
+
+class _Dropout(Function):
+    """y = dropout_p(x) [+ residual]; keep mask from the in-kernel counter-based RNG."""
+
+    @staticmethod
+    def forward(ctx, x, p, residual):
+        xc = cast(x).contiguous()
+        L.require_cuda(xc)
+        rc = None if residual is None else cast(residual).contiguous()
+        y = torch.empty_like(xc)
+        keep = torch.empty(xc.shape, dtype=torch.uint8, device=xc.device)
+        L.check(L.load().mssr_dropout_fwd(xc.data_ptr(), L.ptr(rc), y.data_ptr(), keep.data_ptr(), xc.numel(), p,
+                                          next_seed(), L.dt(xc), L.stream()), "dropout_fwd")
+        ctx.save_for_backward(keep)
+        ctx.scale, ctx.has_res = 1.0 / (1.0 - p), residual is not None
+        ctx.dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        keep, = ctx.saved_tensors
+        dx = _MaskScale.apply(g, keep, ctx.scale)
+        if dx.dtype != ctx.dtype:
+            dx = dx.to(ctx.dtype)
+        return dx, None, (g if ctx.has_res else None)
+
+
+def dropout(x, p, training, residual=None):
+    """dropout(x) (+ residual).  Identity (+ residual) when not training or p == 0."""
+    if training and p > 0.0:
+        return _Dropout.apply(x, float(p), residual)
+    if residual is None:
+        return x
+    return add(x, residual)
+
+
+class _Axpby(Function):
+    """a*x + b*z."""
+
+    @staticmethod
+    def forward(ctx, x, z, a, b):
+        xc = cast(x).contiguous()
+        L.require_cuda(xc)
+        zc = None if z is None else cast(z).contiguous()
+        y = torch.empty_like(xc)
+        L.check(L.load().mssr_axpby(xc.data_ptr(), L.ptr(zc), y.data_ptr(), xc.numel(), a, b, L.dt(xc), L.stream()),
+                "axpby")
+        ctx.a, ctx.b, ctx.has_z = a, b, z is not None
+        ctx.dx, ctx.dz = x.dtype, (None if z is None else z.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = g if ctx.a == 1.0 else _Axpby.apply(g, None, ctx.a, 0.0)
+        gz = None
+        if ctx.has_z:
+            gz = g if ctx.b == 1.0 else _Axpby.apply(g, None, ctx.b, 0.0)
+            if gz.dtype != ctx.dz:
+                gz = gz.to(ctx.dz)
+        if gx.dtype != ctx.dx:
+            gx = gx.to(ctx.dx)
+        return gx, gz, None, None
+
+
+def add(x, z):
+    if x.shape != z.shape:
+        raise ValueError("add: shapes differ %s vs %s" % (tuple(x.shape), tuple(z.shape)))
+    return _Axpby.apply(x, z, 1.0, 1.0)
+
+
+def scale(x, a):
+    return _Axpby.apply(x, None, float(a), 0.0)
+
+
+class _ScaleAddPe(Function):
+    """x*sqrt(d) + pe[pos] (PositionalEncoding.forward, onmt/modules/embeddings.py:48-52)."""
+
+    @staticmethod
+    def forward(ctx, x, pe, step, s):
+        xc = cast(x).contiguous()            # [len, B, d]
+        L.require_cuda(xc, pe)
+        ln, B, d = xc.shape
+        y = torch.empty_like(xc)
+        L.check(L.load().mssr_scale_add_pe(xc.data_ptr(), pe.data_ptr(), y.data_ptr(), ln * B, d, B,
+                                           -1 if step is None else int(step), s, L.dt(xc), L.stream()),
+                "scale_add_pe")
+        ctx.s, ctx.dtype = s, x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        gx = _Axpby.apply(g, None, ctx.s, 0.0)
+        return (gx if gx.dtype == ctx.dtype else gx.to(ctx.dtype)), None, None, None
+
+
+def scale_add_pe(x, pe2d, step, s):
+    return _ScaleAddPe.apply(x, pe2d, step, float(s))
+
+
+class _EmbedPe(Function):
+    """weight[ids]*sqrt(d) + pe[pos]; the padding row gets no gradient (nn.Embedding(padding_idx))."""
+
+    @staticmethod
+    def forward(ctx, ids, weight, pe, step, s, pad_idx):
+        L.require_cuda(ids, weight, pe)
+        ln, B = ids.shape
+        V, d = weight.shape
+        idc = ids.contiguous()
+        w32 = _f32(weight.detach()).contiguous()
+        y = torch.empty(ln, B, d, dtype=_state["dtype"], device=weight.device)
+        L.check(L.load().mssr_embedding_fwd(idc.data_ptr(), w32.data_ptr(), pe.data_ptr(), y.data_ptr(), ln * B, d,
+                                            V, B, -1 if step is None else int(step), s, L.dt(y), L.stream()),
+                "embedding_fwd")
+        ctx.save_for_backward(idc)
+        ctx.shape, ctx.s, ctx.pad, ctx.wdtype = (V, d), s, pad_idx, weight.dtype
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, g):
+        idc, = ctx.saved_tensors
+        V, d = ctx.shape
+        gc = g.contiguous()
+        dw = torch.zeros(V, d, dtype=torch.float32, device=g.device)
+        L.check(L.load().mssr_embedding_bwd(gc.data_ptr(), idc.data_ptr(), dw.data_ptr(), idc.numel(), d, V,
+                                            -1 if ctx.pad is None else int(ctx.pad), ctx.s, L.dt(gc), L.stream()),
+                "embedding_bwd")
+        return None, dw.to(ctx.wdtype), None, None, None, None
+
+
+def embed_pe(ids, weight, pe2d, step, s, pad_idx):
+    return _EmbedPe.apply(ids, weight, pe2d, step, float(s), pad_idx)
+
+
+def attention(q, k, v, mask, p_drop, training):
+    """softmax(mask(q k^T / sqrt(dh))) v on [B,H,L,dh] views; returns (context as a [B,H,Lq,dh]
+    view of [B,Lq,H,dh] memory, probabilities [B,H,Lq,Lk] before dropout) -- onmt/modules/multi_headed_attn.py:187-205."""
+    dh = q.shape[-1]
+    scores = matmul(q, k, tb=True)
+    probs = softmax(scores, mask, 1.0 / math.sqrt(dh))
+    pd = dropout(probs, p_drop, training)
+    return matmul(pd, v, tb=False, heads_last=True), probs

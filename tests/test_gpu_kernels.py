@@ -1,0 +1,409 @@
+"""HIP kernels (through the C ABI / ctypes) against the oracle and the reference's golden vectors.
+
+Tolerances (north_star): fp32 relative 1e-4, bf16 relative 2e-2.  GPU only (-m gpu).
+"""
+import math
+
+import pytest
+import torch
+
+from helpers import assert_close, assert_grads
+from _seeded import seeded_state
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-4
+TOL16 = 2e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mssrnet_style_transfer_amd import ops as o
+    o.set_compute_dtype(torch.float32)
+    yield o
+    o.set_compute_dtype(torch.float32)
+
+
+def dev(x):
+    return x.cuda() if torch.is_tensor(x) else x
+
+
+def gp_probe(g):
+    return ((g.reshape(-1, g.size(-1)).norm(2, dim=1) - 1.0) ** 2).mean()
+
+
+def test_library_loads_and_reports_errors():
+    from mssrnet_style_transfer_amd import _lib
+    lib = _lib.load()
+    assert lib.mssr_abi_version() == 1
+    x = torch.zeros(4, 6, device="cuda")     # d = 6 is not a multiple of 4 -> rejected, nothing launched
+    rc = lib.mssr_layernorm_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                4, 6, 1e-6, 0, None)
+    assert rc != 0 and b"multiple of 4" in lib.mssr_last_error()
+
+
+@pytest.mark.parametrize("d", [64, 256, 512])
+def test_layernorm_golden(ops, golden_ops, d):
+    c = golden_ops["ln_%d" % d]
+    x = dev(c["x"]).requires_grad_()
+    g = dev(c["gamma"]).requires_grad_()
+    b = dev(c["beta"]).requires_grad_()
+    y = ops.layer_norm(x, g, b, 1e-6)
+    assert_close(y, c["y"], TOL32, "y")
+    gx, gg, gb = torch.autograd.grad((y * dev(c["w"])).sum(), (x, g, b), create_graph=True)
+    assert_close(gx, c["gx"], TOL32, "gx")
+    assert_close(gg, c["ggamma"], TOL32, "ggamma")
+    assert_close(gb, c["gbeta"], TOL32, "gbeta")
+    probe = gp_probe(gx)
+    assert_close(probe, c["probe"], TOL32, "probe")
+    g2x, g2g = torch.autograd.grad(probe, (x, g))
+    assert_close(g2x, c["g2x"], TOL32, "g2x")
+    assert_close(g2g, c["g2gamma"], TOL32, "g2gamma")
+
+
+def test_layernorm_bf16_and_dgamma_path(ops):
+    torch.manual_seed(0)
+    x = torch.randn(1000, 512) * 2 + 0.5
+    g, b = torch.randn(512) * 0.3 + 1, torch.randn(512) * 0.3
+    w = torch.randn(1000, 512)
+    xr, gr, br = x.clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = torch.nn.functional.layer_norm(xr, (512,), gr, br, 1e-6)
+    (yr * w).sum().backward()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        xc, gc, bc = x.cuda().requires_grad_(), g.cuda().requires_grad_(), b.cuda().requires_grad_()
+        y = ops.layer_norm(xc, gc, bc, 1e-6)
+        assert y.dtype == torch.bfloat16
+        (y.float() * w.cuda()).sum().backward()
+        assert_close(y.float(), yr, TOL16, "y bf16")
+        assert_close(xc.grad, xr.grad, TOL16, "dx bf16")
+        assert_close(gc.grad, gr.grad, TOL16, "dgamma bf16")
+        assert_close(bc.grad, br.grad, TOL16, "dbeta bf16")
+    finally:
+        ops.set_compute_dtype(torch.float32)
+    # second-order terms through dgamma / dbeta (ggg, ggb inputs of the bwd_bwd kernel), fp32 vs torch
+    x2, g2, b2 = x[:50].clone().requires_grad_(), g.clone().requires_grad_(), b.clone().requires_grad_()
+    w2 = w[:50]
+    y2 = torch.nn.functional.layer_norm(x2, (512,), g2, b2, 1e-6)
+    a1 = torch.autograd.grad((y2 * w2).sum(), (x2, g2, b2), create_graph=True)
+    s_ref = (a1[0] ** 2).sum() + (a1[1] ** 3).sum() + (a1[2] ** 2).sum()
+    r_ref = torch.autograd.grad(s_ref, (x2, g2))
+    xc, gc, bc = x[:50].cuda().requires_grad_(), g.cuda().requires_grad_(), b.cuda().requires_grad_()
+    y = ops.layer_norm(xc, gc, bc, 1e-6)
+    a2 = torch.autograd.grad((y * w2.cuda()).sum(), (xc, gc, bc), create_graph=True)
+    s = (a2[0] ** 2).sum() + (a2[1] ** 3).sum() + (a2[2] ** 2).sum()
+    r = torch.autograd.grad(s, (xc, gc))
+    assert_close(r[0], r_ref[0], TOL32, "g_x via all three")
+    assert_close(r[1], r_ref[1], TOL32, "g_gamma via all three")
+
+
+GEMM_SHAPES = [
+    # (batch dims, M, N, K, a transposed view, b given as [N,K])
+    ((), 80, 512, 512, False, True),
+    ((), 1440, 1024, 512, False, True),
+    ((), 80, 9606, 512, False, True),          # generator Linear, odd N
+    ((), 1440, 256, 9606, False, False),       # soft embedding: K = V, unaligned rows
+    ((), 512, 1024, 1440, True, False),        # dW = dY^T X  (A transposed view)
+    ((), 37, 129, 65, False, True),            # ragged everything
+    ((), 1, 5, 7, False, False),
+    ((5, 8), 18, 18, 64, False, True),         # scores Q K^T per (b, h)
+    ((5, 8), 18, 64, 18, False, False),        # context P V
+    ((3, 4), 130, 130, 32, True, True),
+]
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_gemm_shapes(ops, shape, dtype):
+    bd, M, N, K, ta, tb = shape
+    torch.manual_seed(M * 7 + N * 3 + K)
+    a = torch.randn(*bd, K, M).transpose(-1, -2) if ta else torch.randn(*bd, M, K)
+    b = torch.randn(*bd, N, K) if tb else torch.randn(*bd, K, N)
+    a, b = a.to(dtype), b.to(dtype)
+    ref = a.double() @ (b.double().transpose(-1, -2) if tb else b.double())
+    ac = (a.transpose(-1, -2).contiguous().cuda().transpose(-1, -2) if ta else a.cuda())
+    out = ops.gemm(ac, b.cuda(), tb, dtype)
+    assert_close(out.float(), ref, 1e-5 if dtype == torch.float32 else 1e-2, "gemm %s" % (shape,))
+
+
+def test_gemm_epilogue_and_heads_layout(ops):
+    torch.manual_seed(3)
+    M, N, K = 100, 72, 40
+    a, w, bias = torch.randn(M, K), torch.randn(N, K), torch.randn(N)
+    res, gate = torch.randn(M, N), torch.randn(M, N)
+    ref = torch.relu(a @ w.t() + bias)
+    out = ops.gemm(a.cuda(), w.cuda(), True, torch.float32, bias=bias.cuda(), relu=True)
+    assert_close(out, ref, 1e-5)
+    ref = (a @ w.t() + bias + res) * (gate > 0)
+    out = ops.gemm(a.cuda(), w.cuda(), True, torch.float32, bias=bias.cuda(), residual=res.cuda(),
+                   gate=gate.cuda())
+    assert_close(out, ref, 1e-5)
+    c0 = torch.randn(M, N)
+    out = ops.gemm(a.cuda(), w.cuda(), True, torch.float32, alpha=0.5, beta=1.0, out=c0.cuda())
+    assert_close(out, 0.5 * (a @ w.t()) + c0, 1e-5)
+    # attention layout: operands are [B, L, H, dh] memory viewed [B, H, L, dh]; context stored heads-last
+    B, H, L, dh = 3, 4, 9, 16
+    q = torch.randn(B, L, H * dh).cuda()
+    k = torch.randn(B, L, H * dh).cuda()
+    qv, kv = (t.view(B, L, H, dh).transpose(1, 2) for t in (q, k))
+    s = ops.matmul(qv, kv, tb=True)
+    assert_close(s, torch.matmul(qv, kv.transpose(2, 3)), 1e-5)
+    ctx = ops.matmul(s, kv, tb=False, heads_last=True)
+    assert ctx.permute(0, 2, 1, 3).is_contiguous()
+    assert_close(ctx, torch.matmul(s, kv), 1e-5)
+
+
+def test_softmax_family(ops):
+    torch.manual_seed(5)
+    for n, rows in ((7, 33), (130, 20), (1000, 9), (9606, 11)):
+        x = torch.randn(rows, n) * 3
+        xr = x.clone().requires_grad_()
+        w = torch.randn(rows, n)
+        yr = torch.softmax(xr * 0.7, -1)
+        gr, = torch.autograd.grad((yr * w).sum(), xr, create_graph=True)
+        g2r, = torch.autograd.grad((gr ** 2).sum(), xr)
+        xc = x.cuda().requires_grad_()
+        y = ops.softmax(xc, None, 0.7)
+        g, = torch.autograd.grad((y * w.cuda()).sum(), xc, create_graph=True)
+        g2, = torch.autograd.grad((g ** 2).sum(), xc)
+        assert_close(y, yr, TOL32, "softmax n=%d" % n)
+        assert_close(g, gr, TOL32, "softmax bwd n=%d" % n)
+        assert_close(g2, g2r, TOL32, "softmax bwd_bwd n=%d" % n)
+        ly = ops.log_softmax(xc, 1.3)
+        lr = torch.log_softmax(xr * 1.3, -1)
+        assert_close(ly, lr, TOL32, "log_softmax")
+        gl, = torch.autograd.grad((ly * w.cuda()).sum(), xc)
+        glr, = torch.autograd.grad((lr * w).sum(), xr)
+        assert_close(gl, glr, TOL32, "log_softmax bwd")
+    # masks: [B,1,Lk] and [B,Lq,Lk]; a fully masked row gives a uniform distribution (finite fill)
+    B, H, Lq, Lk = 3, 2, 5, 6
+    s = torch.randn(B, H, Lq, Lk)
+    m1 = torch.zeros(B, 1, Lk, dtype=torch.bool)
+    m1[1, 0, 4:] = True
+    m1[2, 0, :] = True
+    m2 = torch.rand(B, Lq, Lk) > 0.6
+    for m in (m1, m2):
+        ref = torch.softmax(s.masked_fill(m.unsqueeze(1), -1e18), -1)
+        got = ops.softmax(s.cuda(), m.cuda(), 1.0)
+        assert_close(got, ref, TOL32, "masked softmax")
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        y = ops.softmax(s.cuda().bfloat16(), m1.cuda(), 1.0)
+        assert y.dtype == torch.bfloat16
+        assert_close(y.float(), torch.softmax(s.bfloat16().float().masked_fill(m1.unsqueeze(1), -1e18), -1), TOL16)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_dropout_mask_replay_and_stats(ops):
+    torch.manual_seed(1)
+    x = torch.randn(1 << 20, device="cuda").requires_grad_()
+    r = torch.randn(1 << 20, device="cuda")
+    y = ops.dropout(x, 0.1, True, residual=r)
+    kept = ((y - r).detach() != 0).float().mean().item()
+    assert abs(kept - 0.9) < 5e-3
+    g, = torch.autograd.grad(y.sum(), x, create_graph=True)
+    assert_close(g, ((y - r).detach() != 0).float() / 0.9, 1e-6)
+    sel = (y - r).detach() != 0
+    assert_close((y - r)[sel], x.detach()[sel] / 0.9, 1e-6)
+    y2 = ops.dropout(x, 0.1, True)
+    assert not torch.equal((y2 != 0), sel)               # a fresh mask per call
+    assert torch.equal(ops.dropout(x, 0.1, False), x)    # eval: identity
+    xo = torch.randn(1003, device="cuda")                # odd length tail
+    yo = ops.dropout(xo, 0.5, True)
+    nz = yo != 0
+    assert_close(yo[nz], xo[nz] * 2, 1e-6)
+
+
+def test_embedding_and_pe(ops, golden_ops):
+    from mssrnet_style_transfer_amd.modules.embeddings import Embeddings
+    e = golden_ops["emb"]
+    emb = Embeddings(64, 50, 1, position_encoding=True, dropout=0.0)
+    emb.load_state_dict(e["sd"])
+    emb.cuda()
+    W = emb.word_lut.weight
+    y = emb(dev(e["ids"]))
+    assert_close(y, e["y_ids"], TOL32)
+    g, = torch.autograd.grad((y * dev(e["w"])).sum(), W)
+    assert_close(g, e["g_ids_w"], TOL32)
+    soft = dev(e["soft"]).requires_grad_()
+    y = emb(soft)
+    assert_close(y, e["y_soft"], TOL32)
+    gi, gw = torch.autograd.grad((y * dev(e["w"])).sum(), (soft, W))
+    assert_close(gi, e["g_soft_in"], TOL32)
+    assert_close(gw, e["g_soft_w"], TOL32)
+    assert_close(emb(soft[2:3], step=2), e["y_soft_step2"], TOL32)
+    c = golden_ops["pe"]
+    pe = emb.make_embedding[1]
+    assert_close(pe(dev(c["emb"])), c["full"], TOL32)
+    assert_close(pe(dev(c["emb"])[:1], step=3), c["step3"], TOL32)
+
+
+def mha_template(d):
+    t = {}
+    for n in ("linear_keys", "linear_values", "linear_query", "final_linear"):
+        t[n + ".weight"] = torch.empty(d, d)
+        t[n + ".bias"] = torch.empty(d)
+    return t
+
+
+def run_mha(c, dtype=torch.float32):
+    from mssrnet_style_transfer_amd.modules.multi_headed_attn import MultiHeadedAttention
+    d = c["d"]
+    m = MultiHeadedAttention(c["H"], d, dropout=0.0)
+    m.load_state_dict(c["sd"] if c["sd"] is not None else seeded_state(mha_template(d), c["seed"]))
+    m.cuda()
+    ins = {k: dev(v).requires_grad_() for k, v in c["inputs"].items()}
+    if "x" in ins:
+        key = value = query = ins["x"]
+        at = "self"
+    else:
+        key = value = ins["mem"]
+        query = ins["q"]
+        at = "context"
+    o, attn = m(key, value, query, mask=dev(c["mask"]), attn_type=at)
+    return m, ins, o, attn
+
+
+@pytest.mark.parametrize("name", ["self_pad", "self_causal", "cross", "nomask", "self_pad_d256", "cross_d512"])
+def test_mha_golden_fp32(ops, golden_ops, name):
+    c = golden_ops["mha_" + name]
+    m, ins, o, attn = run_mha(c)
+    assert_close(o, c["out"], TOL32, "out")
+    assert_close(attn, c["attn"], TOL32, "attn")
+    names = list(ins.keys()) + [n for n, _ in m.named_parameters()]
+    tens = list(ins.values()) + list(m.parameters())
+    scalar = (o * dev(c["wo"])).sum() + (attn * dev(c["wa"])).sum()
+    g = torch.autograd.grad(scalar, tens, create_graph=True)
+    assert_grads(dict(zip(names, g)), c["g"], TOL32, "g")
+    probe = sum(gp_probe(gi) for gi in g[:len(ins)])
+    assert_close(probe, c["probe"], TOL32, "probe")
+    g2 = torch.autograd.grad(probe, tens, allow_unused=True)
+    assert_grads(dict(zip(names, g2)), c["g2"], 2e-4, "g2")
+
+
+def test_mha_bf16(ops, golden_ops):
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        for name in ("self_pad", "cross_d512"):
+            c = golden_ops["mha_" + name]
+            m, ins, o, attn = run_mha(c)
+            assert o.dtype == torch.bfloat16
+            assert_close(o.float(), c["out"], TOL16, "out bf16")
+            assert_close(attn.float(), c["attn"], TOL16, "attn bf16")
+            tens = list(ins.values()) + list(m.parameters())
+            names = list(ins.keys()) + [n for n, _ in m.named_parameters()]
+            scalar = (o.float() * dev(c["wo"])).sum() + (attn.float() * dev(c["wa"])).sum()
+            g = torch.autograd.grad(scalar, tens)
+            for n_, t in zip(names, g):
+                assert t.dtype == torch.float32
+            assert_grads(dict(zip(names, g)), c["g"], 4e-2, "g bf16", floor_rel=2e-2)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_mha_cached(ops, golden_ops):
+    from mssrnet_style_transfer_amd.modules.multi_headed_attn import MultiHeadedAttention
+    c = golden_ops["mha_cached"]
+    ms, mc = MultiHeadedAttention(c["H"], 64, 0.0), MultiHeadedAttention(c["H"], 64, 0.0)
+    ms.load_state_dict(c["sd_self"])
+    mc.load_state_dict(c["sd_ctx"])
+    ms.cuda()
+    mc.cuda()
+    mem = dev(c["mem"])
+    mask = ~(torch.arange(mem.size(1), device="cuda").unsqueeze(0) < dev(c["lens"]).unsqueeze(1)).unsqueeze(1)
+    cache = {"self_keys": None, "self_values": None, "memory_keys": None, "memory_values": None}
+    for st in c["steps"]:
+        q = dev(st["q"])
+        o1, a1 = ms(q, q, q, mask=None, layer_cache=cache, attn_type="self")
+        o2, a2 = mc(mem, mem, q, mask=mask, layer_cache=cache, attn_type="context")
+        assert_close(o1, st["self_out"], TOL32)
+        assert_close(a1, st["self_attn"], TOL32)
+        assert_close(o2, st["ctx_out"], TOL32)
+        assert_close(a2, st["ctx_attn"], TOL32)
+    for k, v in c["cache"].items():
+        assert_close(cache[k], v, TOL32, k)
+
+
+def ffn_template(d, ff):
+    return {"w_1.weight": torch.empty(ff, d), "w_1.bias": torch.empty(ff), "w_2.weight": torch.empty(d, ff),
+            "w_2.bias": torch.empty(d), "layer_norm.weight": torch.empty(d), "layer_norm.bias": torch.empty(d)}
+
+
+@pytest.mark.parametrize("d", [64, 256])
+def test_ffn_golden(ops, golden_ops, d):
+    from mssrnet_style_transfer_amd.modules.position_ffn import PositionwiseFeedForward
+    c = golden_ops["ffn_%d" % d]
+    ff = c["ff"] if c["sd"] is None else c["sd"]["w_1.weight"].shape[0]
+    m = PositionwiseFeedForward(d, ff, 0.0)
+    m.load_state_dict(c["sd"] if c["sd"] is not None else seeded_state(ffn_template(d, ff), c["seed"]))
+    m.cuda()
+    x = dev(c["x"]).requires_grad_()
+    y = m(x)
+    assert_close(y, c["y"], TOL32, "y")
+    names = ["x"] + [n for n, _ in m.named_parameters()]
+    tens = [x] + list(m.parameters())
+    g = torch.autograd.grad((y * dev(c["w"])).sum(), tens, create_graph=True)
+    assert_grads(dict(zip(names, g)), c["g"], TOL32, "g")
+    g2 = torch.autograd.grad(gp_probe(g[0]), tens, allow_unused=True)
+    assert_grads(dict(zip(names, g2)), c["g2"], 2e-4, "g2")
+
+
+def test_encoder_golden(ops, golden_modules):
+    from mssrnet_style_transfer_amd.encoders.transformer import TransformerEncoder
+    from mssrnet_style_transfer_amd.modules.embeddings import Embeddings
+    c = golden_modules["encoder"]
+    enc = TransformerEncoder(2, 64, 4, 128, 0.0, 0.0, Embeddings(64, 200, 1, position_encoding=True), 0)
+    enc.load_state_dict(c["sd"])
+    enc.cuda()
+    emb, mem, _ = enc(dev(c["src"]), dev(c["lens"]))
+    assert_close(emb, c["emb"], TOL32)
+    assert_close(mem, c["mem"], TOL32)
+    (mem * dev(c["w"])).sum().backward()
+    assert_grads({k: p.grad for k, p in enc.named_parameters()}, c["g"], TOL32, "enc")
+    soft = dev(c["soft"]).requires_grad_()
+    _, mem2, _ = enc(soft, dev(c["lens"]))
+    assert_close(mem2, c["mem_soft"], TOL32)
+    gs, = torch.autograd.grad((mem2 * dev(c["w"])).sum(), soft)
+    assert_close(gs, c["g_soft_in"], TOL32)
+
+
+def test_decoder_golden(ops, golden_modules):
+    from mssrnet_style_transfer_amd.decoders.transformer import TransformerDecoder
+    from mssrnet_style_transfer_amd.modules.embeddings import Embeddings
+    c = golden_modules["decoder"]
+    dec = TransformerDecoder(2, 64, 4, 128, False, "scaled-dot", 0.0, 0.0, Embeddings(64, 200, 1, position_encoding=True),
+                             0, False, False, -3, 0)
+    dec.load_state_dict(c["sd"])
+    dec.cuda()
+    src, lens = dev(c["src"]), dev(c["lens"])
+    memory = dev(c["memory"]).requires_grad_()
+    dec.init_state(src, memory, None)
+    outs, attns = dec(dev(c["tgt"]), memory, memory_lengths=lens)
+    assert_close(outs, c["dec_outs"], TOL32)
+    assert_close(attns["std"], c["attn_std"], TOL32)
+    ((outs * dev(c["w"])).sum() + attns["std"].sum() * 0.1).backward()
+    assert_grads({k: p.grad for k, p in dec.named_parameters()}, c["g"], TOL32, "dec")
+    assert_close(memory.grad, c["g_memory"], TOL32)
+    # step-wise with soft inputs, gradient through the growing cache
+    dec.zero_grad()
+    memory.grad = None
+    dec.init_state(src, memory, None)
+    so, sa = [], []
+    soft_in = dev(c["soft_in"])
+    for s in range(soft_in.size(0)):
+        o, a = dec(soft_in[s:s + 1], memory, memory_lengths=lens, step=s)
+        so.append(o)
+        sa.append(a["std"])
+    so = torch.cat(so, 0)
+    assert_close(so, c["step_outs"], TOL32)
+    assert_close(torch.cat(sa, 0), c["step_attn"], TOL32)
+    (so * dev(c["ws"])).sum().backward()
+    assert_grads({k: p.grad for k, p in dec.named_parameters()}, c["g_step"], TOL32, "dec_step")
+    assert_close(memory.grad, c["g_step_memory"], TOL32)
+    for k, v in c["cache0"].items():
+        assert_close(dec.state["cache"]["layer_0"][k], v, TOL32, k)
+    dec.init_state(src, memory, None)
+    with torch.no_grad():
+        ids = torch.cat([dec(dev(c["tgt"])[s:s + 1], memory, memory_lengths=lens, step=s)[0] for s in range(4)], 0)
+    assert_close(ids, c["id_step_outs"], TOL32)
