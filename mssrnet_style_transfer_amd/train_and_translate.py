@@ -1,0 +1,63 @@
+"""Differentiable step-wise soft decoding used inside the training step.
+
+Counterpart of onmt/train_and_translate.py: ``decode_batch_ori`` (:202-231),
+``_decode_and_generate`` (:95-116) and ``fetch_dec_output_length`` (:289-326).  The decoder is
+driven one step at a time with the previous step's probabilities as (soft) input, through the
+module-level cache protocol of TransformerDecoder.
+"""
+import torch
+
+from . import ops
+
+
+def convert_to_onehot(labels, vocab_size, device, dtype=torch.float32):
+    """onmt/tensor_utils.py:14-23."""
+    return torch.zeros(labels.size(0), vocab_size, device=device, dtype=dtype).scatter_(1, labels.unsqueeze(1), 1)
+
+
+def generator_probs(model, dec_out, temperature=1.0, log=False):
+    """generator[0] Linear -> fp32 -> softmax(/T) (or log-softmax): train_and_translate.py:110-115,
+    trainer_wgan_wh.py:659-664."""
+    lin = model.generator[0]
+    logits = ops.linear(dec_out, lin.weight, lin.bias)
+    if log:
+        return ops.log_softmax(logits, 1.0 / temperature, out_dtype=torch.float32)
+    return ops.softmax(logits, None, 1.0 / temperature, out_dtype=torch.float32)
+
+
+def fetch_dec_output_length(vocab_probs, cfg):
+    """Host-side length rule: first </s> (or . ! ? when sent_stop_aware) + 1, 'cut <= 1' and the
+    longest sentence forced to seq_len (train_and_translate.py:289-326)."""
+    seq_len = vocab_probs.size(0)
+    ids = torch.argmax(vocab_probs, 2)
+    rows = ids.transpose(0, 1).tolist()
+    stops = [cfg.eos_idx] + ([cfg.dot_idx, cfg.excl_idx, cfg.qst_idx] if cfg.sent_stop_aware else [])
+    lens, best, best_i = [], 0, 0
+    for i, sent in enumerate(rows):
+        cut = min([sent.index(s) + 1 for s in stops if s in sent] + [seq_len])
+        if cut <= 1:
+            cut = seq_len
+        lens.append(cut)
+        if cut > best:
+            best, best_i = cut, i
+    lens[best_i] = seq_len
+    return lens, ids
+
+
+def decode_batch_ori(model, cfg, src, enc_states, memory_bank, src_lengths, max_dec_steps=None):
+    """Returns (vocab_probs [steps,B,V] fp32, seq_lens list, pred_ids [steps,B])."""
+    if max_dec_steps is None:
+        max_dec_steps = cfg.max_dec_steps
+    B = src_lengths.size(0)
+    model.decoder.init_state(src, memory_bank, enc_states)
+    bos = torch.full((B,), cfg.bos_idx, dtype=torch.long, device=src.device)
+    decoder_input = convert_to_onehot(bos, cfg.vocab_size, src.device).unsqueeze(0)
+    outs = []
+    for step in range(max_dec_steps):
+        dec_out, _ = model.decoder(decoder_input, memory_bank, memory_lengths=src_lengths, step=step)
+        probs = generator_probs(model, dec_out, cfg.dec_temperature)
+        outs.append(probs[-1:])
+        decoder_input = outs[-1]
+    vocab_probs = torch.cat(outs, 0)
+    seq_lens, pred_ids = fetch_dec_output_length(vocab_probs, cfg)
+    return vocab_probs, seq_lens, pred_ids

@@ -1,0 +1,315 @@
+"""The WGAN-GP training phases of MSSRNet driven over the gfx950 modules.
+
+Counterpart of onmt/trainer_wgan_wh.py (``train_discriminator`` :505-629, ``train_generator``
+:865-982, ``train_reconstruct`` :729-863, ``init_launch`` :465-503, penalties :1217-1331,
+``cal_disc_loss`` :1192-1200) and of the teacher step (onmt/trainer_teacher.py:229-267), for
+the README flag set (README.md:54-84; carried by ``MSSRConfig``).  Same order of forwards and
+backwards, ``no_grad`` regions, train/eval modes, losses, clipping and Adam settings; logged
+scalars are returned as a dict instead of going to InfoLogger / TensorBoard.
+
+Data parallelism: ``grad_sync`` (see parallel.py) is called once per optimizer step, after the
+last backward of the phase and before clipping, with the networks that are about to step.
+"""
+import torch
+import torch.nn.functional as F
+from torch.nn.utils import clip_grad_norm_
+
+from .train_and_translate import decode_batch_ori, generator_probs
+from .utils.misc import sequence_mask
+
+
+def cal_disc_loss(probs, labels):
+    """probs[i, labels[i]] as a [N] tensor (one gather instead of the reference's per-row loop)."""
+    idx = torch.as_tensor(labels, device=probs.device).view(-1, 1)
+    return probs.gather(1, idx).squeeze(1)
+
+
+def convert_sent_ids_to_onehot(sent_ids, vocab_size):
+    B, L = sent_ids.shape
+    oh = torch.zeros(B * L, vocab_size, device=sent_ids.device)
+    return oh.scatter_(1, sent_ids.reshape(-1, 1), 1).view(B, L, vocab_size)
+
+
+def penalize_gen_style_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.0, gp_norm_seq=True):
+    """real/fake [B, L, dim]; alpha is drawn from the CPU generator exactly as the reference does
+    (torch.rand(B,1,1).type_as(real), trainer_wgan_wh.py:1238)."""
+    alpha = torch.rand(real.size(0), 1, 1).to(real)
+    inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
+    err = cal_disc_loss(d_model(inter, lengths), labels)
+    g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+    if gp_norm_seq:
+        g = g.contiguous().view(-1, g.size(-1))[sequence_mask(lengths).contiguous().view(-1)]
+    return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
+
+
+def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.0, gp_norm_seq=True):
+    """real/fake [B, T, V]; the critic takes [T, B, V] (trainer_wgan_wh.py:1283-1331)."""
+    x_len = real.size(1)
+    alpha = torch.rand(real.size(0), 1, 1).to(real)
+    inter = (alpha * real + (1 - alpha) * fake).transpose(0, 1).detach().requires_grad_(True)
+    err = cal_disc_loss(d_model(inter, lengths), labels)
+    g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+    g = g.transpose(0, 1)
+    if gp_norm_seq:
+        g = g.contiguous().view(-1, g.size(-1))[sequence_mask(lengths, max_len=x_len).contiguous().view(-1)]
+    return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
+
+
+class Trainer:
+    def __init__(self, nets, cfg, grad_sync=None):
+        self.cfg = cfg
+        self.model = nets["model"]
+        self.style_generator = nets["style_generator"]
+        self.style_discriminator = nets["style_discriminator"]
+        self.text_discriminator = nets["text_discriminator"]
+        self.classifier = nets["teacher"]
+        self.classifier.eval()
+        self.grad_sync = grad_sync
+        adam = lambda m: torch.optim.Adam(m.parameters(), lr=cfg.learning_rate,  # noqa: E731
+                                          betas=(cfg.adam_beta1, cfg.adam_beta2))
+        self.style_generator_optim = adam(self.style_generator)
+        self.style_discriminator_optim = adam(self.style_discriminator)
+        self.text_discriminator_optim = adam(self.text_discriminator)
+        self.model_optim = adam(self.model)
+        dev = next(self.model.parameters()).device
+        self.one = torch.ones([], device=dev)
+        self.mone = -torch.ones([], device=dev)
+        self.pad_tensor = torch.full((1, 1, 1), cfg.pad_idx, dtype=torch.long, device=dev)
+
+    # ------------------------------------------------------------------ pieces
+    def _gain(self, logits, mode):
+        if mode == "normal":
+            return logits
+        if mode == "sigmoid":
+            return torch.sigmoid(logits) * self.cfg.gain_ratio
+        raise ValueError("unsupported force_positive_gain_mode: %s" % mode)
+
+    def _call_text_discriminator(self, x, lengths):
+        return self._gain(self.text_discriminator(x, lengths), self.cfg.gain_mode_t)
+
+    def _call_style_discriminator(self, x, lengths):
+        return self._gain(self.style_discriminator(x, lengths), self.cfg.gain_mode_s)
+
+    def unpack_batch(self, batch):
+        cfg = self.cfg
+        src, src_lengths = batch.src, batch.src_lengths
+        real_src = src[1:]
+        real_len = src_lengths - 1
+        labels_list = [cfg.label_token_ids.index(t) for t in src[0, :, 0].tolist()]
+        labels = torch.tensor(labels_list, dtype=torch.long, device=src.device)
+        vocab_target = torch.cat([batch.tgt[1:], self.pad_tensor.repeat(1, batch.tgt.size(1), 1)])
+        return labels, labels_list, real_src, real_len, vocab_target
+
+    def vocab_loss(self, log_probs, target, batch_size):
+        """VocabLossFn(token_mode=False, all_tokens_aware=sent_stop_aware), onmt/train_util.py:13-32."""
+        ignore = -100 if self.cfg.sent_stop_aware else self.cfg.pad_idx
+        return F.nll_loss(log_probs, target, ignore_index=ignore, reduction="sum") / batch_size
+
+    def vocab_loss_from_probs(self, probs, target, batch_size):
+        """The same loss on probabilities: NLL(log p) only reads p at the target ids, so the log is
+        taken after the gather (T*B values) instead of over the whole [T*B, V] tensor."""
+        p = probs.reshape(-1, probs.size(-1)).gather(1, target.view(-1, 1)).squeeze(1)
+        nll = -p.log()
+        if not self.cfg.sent_stop_aware:
+            nll = nll * target.ne(self.cfg.pad_idx).to(nll.dtype)
+        return nll.sum() / batch_size
+
+    def cal_style_gap(self, real, gen, lengths):
+        gap = ((real.float() - gen.float()) ** 2).sum(2).transpose(0, 1)
+        return gap[sequence_mask(lengths, max_len=real.size(0))].mean()
+
+    def _gen_real_style_represents(self, real_src, real_len):
+        with torch.no_grad():
+            _, memory_bank, _ = self.classifier.encoder(real_src, real_len)
+        return memory_bank.detach()
+
+    def _gen_style_represents(self, desired, real_src, real_len):
+        return self.style_generator(desired, real_src, real_len)
+
+    def _encode(self, real_src, real_len, style_rep):
+        enc_state, memory_bank, lengths = self.model.encoder(real_src, real_len)
+        return enc_state, self.model.bond_layer(memory_bank, style_rep), lengths
+
+    def _self_reconstruct(self, real_src, real_len, tgt, style_rep):
+        enc_state, mem, lengths = self._encode(real_src, real_len, style_rep)
+        self.model.decoder.init_state(real_src, mem, enc_state)
+        dec_out, _ = self.model.decoder(tgt, mem, memory_lengths=lengths)
+        return generator_probs(self.model, dec_out, self.cfg.dec_temperature, log=True)
+
+    def _dynamic_decoding(self, real_src, real_len, style_rep, max_dec_steps):
+        enc_state, mem, _ = self._encode(real_src, real_len, style_rep)
+        probs, lens, ids = decode_batch_ori(self.model, self.cfg, real_src, enc_state, mem, real_len, max_dec_steps)
+        return probs, torch.tensor(lens, dtype=torch.long, device=real_len.device), ids
+
+    def _finish(self, modules, optims, clip=True):
+        if self.grad_sync is not None:
+            self.grad_sync(modules)
+        if clip and self.cfg.max_grad_norm > 0:
+            for m in modules:
+                clip_grad_norm_(m.parameters(), self.cfg.max_grad_norm)
+        for o in optims:
+            o.step()
+
+    # ------------------------------------------------------------------ phases
+    def train_discriminator(self, batch):
+        cfg = self.cfg
+        self.style_generator.eval()
+        self.model.eval()
+        self.style_discriminator.train()
+        self.text_discriminator.train()
+        self.style_discriminator_optim.zero_grad()
+        self.text_discriminator_optim.zero_grad()
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        text_len = (real_len + 1).detach()
+        if cfg.discr_sent_stop_aware:
+            text_len = torch.ones_like(real_len) * vocab_target.size(0)
+        # text critic: real / fake / gradient penalty
+        gain_t_real = cal_disc_loss(self._call_text_discriminator(vocab_target, text_len), labels_list).mean()
+        gain_t_real.backward(self.mone)
+        with torch.no_grad():
+            rep = self._gen_style_represents(labels, real_src, real_len)
+            probs, _, _ = self._dynamic_decoding(real_src, real_len, rep, vocab_target.size(0))
+        gain_t_fake = cal_disc_loss(self._call_text_discriminator(probs, text_len), labels_list).mean()
+        gain_t_fake.backward(self.one)
+        with torch.no_grad():
+            probs_t = probs.transpose(0, 1)
+            real_onehot = convert_sent_ids_to_onehot(vocab_target.transpose(0, 1).squeeze(2), cfg.vocab_size)
+        t_gp = penalize_gen_text_grad(self._call_text_discriminator, real_onehot, probs_t, text_len, labels_list,
+                                      k=cfg.wgan_text_k, lamb=cfg.wgan_text_lamb, gp_norm_seq=cfg.use_gp_norm_seq)
+        t_gp.backward()
+        # style critic
+        real_rep_t = self._gen_real_style_represents(real_src, real_len).transpose(0, 1)
+        gain_s_real = cal_disc_loss(self._call_style_discriminator(real_rep_t, real_len), labels_list).mean()
+        gain_s_real.backward(self.mone)
+        with torch.no_grad():
+            gen_rep_t = self._gen_style_represents(labels, real_src, real_len).transpose(0, 1)
+        gain_s_fake = cal_disc_loss(self._call_style_discriminator(gen_rep_t, real_len), labels_list).mean()
+        gain_s_fake.backward(self.one)
+        s_gp = penalize_gen_style_grad(self._call_style_discriminator, real_rep_t.float(), gen_rep_t.float(),
+                                       real_len, labels_list, k=cfg.wgan_style_k, lamb=cfg.wgan_style_lamb,
+                                       gp_norm_seq=cfg.use_gp_norm_seq)
+        s_gp.backward()
+        self._finish((self.style_discriminator, self.text_discriminator),
+                     (self.style_discriminator_optim, self.text_discriminator_optim))
+        v = torch.stack([gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp]).tolist()   # one sync
+        return dict(TR_gain=v[0], TF_gain=v[1], T_gp=v[2], T_cost=v[1] - v[0] + v[2], T_Wgap=v[0] - v[1],
+                    SR_gain=v[3], SF_gain=v[4], S_gp=v[5], S_cost=v[4] - v[3] + v[5], S_Wgap=v[3] - v[4])
+
+    def train_generator(self, batch):
+        cfg = self.cfg
+        self.style_generator.train()
+        self.model.train()
+        self.style_discriminator.eval()
+        self.text_discriminator.eval()
+        self.style_generator_optim.zero_grad()
+        self.model_optim.zero_grad()
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        tgt_len, B = vocab_target.size(0), vocab_target.size(1)
+        desired = 1 - labels                                   # num_styles == 2 (train_and_translate.py:72-73)
+        desired_list = desired.tolist()
+        max_dec_steps = tgt_len + cfg.max_extra_dec_steps
+        log = {}
+        rep = self._gen_style_represents(desired, real_src, real_len)
+        probs, seq_lens, _ = self._dynamic_decoding(real_src, real_len, rep, max_dec_steps)
+        lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
+        gain_t = cal_disc_loss(self._call_text_discriminator(probs, lens), desired_list).mean()
+        gain_t.backward(self.mone * cfg.text_ap_scale)
+        with torch.no_grad():
+            acc = self.classifier(probs, lens).argmax(-1).eq(desired).float().mean()
+        rep2_t = self._gen_style_represents(desired, real_src, real_len).transpose(0, 1)
+        gain_s = cal_disc_loss(self._call_style_discriminator(rep2_t, real_len), desired_list).mean()
+        gain_s.backward(self.mone * cfg.style_ap_scale)
+        vals = [gain_t, acc, gain_s]
+        if cfg.ap_gen_self_style_text:
+            rep3 = self._gen_style_represents(labels, real_src, real_len)
+            sprobs, _, _ = self._dynamic_decoding(real_src, real_len, rep3, tgt_len)
+            vl = self.vocab_loss_from_probs(sprobs, vocab_target.contiguous().view(-1), B)
+            vl.backward()
+            vals.append(vl)
+        self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
+        v = torch.stack([t.detach().float() for t in vals]).tolist()
+        log.update(AT_gain=v[0], AT_acc=v[1], AS_gain=v[2])
+        if cfg.ap_gen_self_style_text:
+            log.update(T_selfstyle_vloss=v[3])
+        return log
+
+    def train_reconstruct(self, batch):
+        cfg = self.cfg
+        self.style_generator.train()
+        self.model.train()
+        self.style_generator_optim.zero_grad()
+        self.model_optim.zero_grad()
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        tgt_len, B = vocab_target.size(0), vocab_target.size(1)
+        flat_target = vocab_target.contiguous().view(-1)
+        desired = 1 - labels
+        max_dec_steps = tgt_len + cfg.max_extra_dec_steps
+        real_rep = self._gen_real_style_represents(real_src, real_len)
+        lp = self._self_reconstruct(real_src, real_len, batch.tgt, real_rep)         # sr_noise_prob == 0
+        l_noised = self.vocab_loss(lp.view(-1, lp.size(-1)), flat_target, B)
+        total = cfg.sr_loss_ratio * l_noised
+        rep_src = self._gen_style_represents(labels, real_src, real_len)
+        rep_tgt = self._gen_style_represents(desired, real_src, real_len)
+        probs, _, _ = self._dynamic_decoding(real_src, real_len, rep_src, tgt_len)
+        l_rec = self.vocab_loss_from_probs(probs, flat_target, B)
+        total = total + cfg.sr_loss_ratio * l_rec
+        names, vals = ["T_CONSTRUCT_R_VL", "T_CONSTRUCT_F_VL"], [l_noised, l_rec]
+        if cfg.use_cls_feedback:
+            s_src = self.classifier.do_cls(rep_src.transpose(0, 1), real_len)
+            l_s_src = F.nll_loss(F.log_softmax(s_src, -1), labels)
+            s_tgt = self.classifier.do_cls(rep_tgt.transpose(0, 1), real_len)
+            l_s_tgt = F.nll_loss(F.log_softmax(s_tgt, -1), desired)
+            total = total + cfg.cls_loss_ratio * l_s_src + cfg.cls_loss_ratio * l_s_tgt
+        if not cfg.without_stl_penalty:
+            l_gap = self.cal_style_gap(real_rep, rep_src, real_len)
+            total = total + cfg.alpha_style_gap * l_gap
+        if cfg.use_cls_feedback:
+            cprobs, clens, _ = self._dynamic_decoding(real_src, real_len, rep_tgt, max_dec_steps)
+            t_logits = self.classifier(cprobs, clens)
+            l_t = F.nll_loss(F.log_softmax(t_logits, -1), desired)
+            total = total + cfg.cls_loss_ratio * l_t
+            names += ["T_CLS_loss", "T_CLS_acc", "S_CLS_loss", "S_CLS_acc", "SCur_CLS_loss", "SCur_CLS_acc"]
+            vals += [l_t, t_logits.argmax(-1).eq(desired).float().mean(), l_s_tgt,
+                     s_tgt.argmax(-1).eq(desired).float().mean(), l_s_src,
+                     s_src.argmax(-1).eq(labels).float().mean()]
+        if not cfg.without_stl_penalty:
+            names.append("S_GAP_loss")
+            vals.append(l_gap)
+        total.backward()
+        # no clipping in this phase; the style generator steps only if it received a loss (:859-863)
+        optims = [self.model_optim]
+        if cfg.use_cls_feedback or not cfg.without_stl_penalty:
+            optims.insert(0, self.style_generator_optim)
+        self._finish((self.style_generator, self.model), optims, clip=False)
+        return dict(zip(names, torch.stack([t.detach().float() for t in vals]).tolist()))
+
+    def init_launch(self, batch):
+        self.style_generator.train()
+        self.model.train()
+        self.style_generator_optim.zero_grad()
+        self.model_optim.zero_grad()
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        B = len(labels_list)
+        real_rep = self._gen_real_style_represents(real_src, real_len)
+        l_style = self.cal_style_gap(real_rep, self._gen_style_represents(labels, real_src, real_len), real_len)
+        l_style.backward()
+        lp = self._self_reconstruct(real_src, real_len, batch.tgt, real_rep)
+        l_v = self.vocab_loss(lp.view(-1, lp.size(-1)), vocab_target.contiguous().view(-1), B)
+        l_v.backward()
+        self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
+        v = torch.stack([l_style.detach(), l_v.detach()]).tolist()
+        return dict(INIT_SL=v[0], INIT_VL=v[1])
+
+
+def teacher_step_loss(classifier, batch, cfg):
+    """onmt/trainer_teacher.py:238-252: three forwards (ids / ids+</s> / full padded length), NLL summed."""
+    src, src_lengths = batch.src, batch.src_lengths
+    real_src, real_len = src[1:], src_lengths - 1
+    labels = torch.tensor([cfg.label_token_ids.index(t) for t in src[0, :, 0].tolist()], device=src.device)
+    pad_row = torch.full((1, batch.tgt.size(1), 1), cfg.pad_idx, dtype=torch.long, device=src.device)
+    new_x = torch.cat([batch.tgt[1:], pad_row])
+    nll = lambda lg: F.nll_loss(F.log_softmax(lg, -1), labels)  # noqa: E731
+    logits = classifier(real_src, real_len)
+    loss = nll(logits) + nll(classifier(new_x, real_len + 1))
+    loss = loss + nll(classifier(new_x, torch.ones_like(src_lengths) * new_x.size(0)))
+    return loss, logits

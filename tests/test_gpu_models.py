@@ -1,0 +1,176 @@
+"""Callers of the hot path on the GPU (critics, style generator, soft decode, the four
+training phases, teacher step) against the golden vectors the reference produced.
+
+fp32 compute, dropout 0, tolerance 1e-4 relative on losses and gradients (north_star); the
+bf16 run of the phases is checked at 2e-2 on the logged losses.
+"""
+import random
+from types import SimpleNamespace
+
+import pytest
+import torch
+
+from helpers import assert_close, assert_grads, assert_post_step
+from mssrnet_style_transfer_amd.config import MSSRConfig
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from mssrnet_style_transfer_amd import ops as o
+    o.set_compute_dtype(torch.float32)
+    yield o
+    o.set_compute_dtype(torch.float32)
+
+
+def dev(x):
+    return x.cuda() if torch.is_tensor(x) else x
+
+
+def grads_of(m):
+    return {k: p.grad for k, p in m.named_parameters()}
+
+
+def test_style_modules(ops, golden_modules):
+    from mssrnet_style_transfer_amd import style_generator_builder as B
+    from mssrnet_style_transfer_amd import trainer_wgan_wh as T
+    cfg = MSSRConfig.small()
+    c = golden_modules["style_generator"]
+    sg = B.build_style_generator(cfg)
+    sg.load_state_dict(c["sd"])
+    sg.cuda()
+    rep = sg(dev(c["desired"]), dev(c["src"]), dev(c["lens"]))
+    assert_close(rep, c["rep"], TOL)
+    (rep * dev(c["w"])).sum().backward()
+    assert_grads(grads_of(sg), c["g"], TOL, "sgen")
+
+    c = golden_modules["text_disc"]
+    td = B.build_text_discriminator(cfg)
+    td.load_state_dict(c["sd"])
+    td.cuda()
+    logits = td(dev(c["src"]), dev(c["lens"]))
+    assert_close(logits, c["logits"], TOL)
+    logits.sum().backward()
+    assert_grads(grads_of(td), c["g"], TOL, "tdisc")
+    assert_close(td(dev(c["fake"]), dev(c["tlen"])), c["soft_logits"], TOL)
+    td.zero_grad()
+    onehot = T.convert_sent_ids_to_onehot(dev(c["vocab_target"]).transpose(0, 1).squeeze(2), cfg.vocab_size)
+    torch.manual_seed(c["gp_seed"])
+    gp = T.penalize_gen_text_grad(lambda x, l: torch.sigmoid(td(x, l)), onehot, dev(c["fake"]).transpose(0, 1),
+                                  dev(c["tlen"]), c["labels"].tolist(), 1.0, 10.0, True)
+    assert_close(gp, c["gp"], TOL)
+    gp.backward()
+    assert_grads(grads_of(td), c["g_gp"], 2e-4, "tdisc_gp")
+
+    c = golden_modules["style_disc"]
+    sd = B.build_style_discriminator(cfg)
+    sd.load_state_dict(c["sd"])
+    sd.cuda()
+    lg = sd(dev(c["real"]), dev(c["lens"]))
+    assert_close(lg, c["logits"], TOL)
+    lg.sum().backward()
+    assert_grads(grads_of(sd), c["g"], TOL, "sdisc")
+    sd.zero_grad()
+    torch.manual_seed(c["gp_seed"])
+    gp = T.penalize_gen_style_grad(lambda x, l: torch.sigmoid(sd(x, l)), dev(c["real"]), dev(c["fake"]),
+                                   dev(c["lens"]), c["labels"].tolist(), 1.0, 10.0, True)
+    assert_close(gp, c["gp"], TOL)
+    gp.backward()
+    assert_grads(grads_of(sd), c["g_gp"], 2e-4, "sdisc_gp")
+
+    c = golden_modules["bond"]
+    bond = B.BondLayer(cfg.d_sgen, cfg.d_model)
+    bond.load_state_dict(c["sd"])
+    bond.cuda()
+    assert_close(bond(dev(c["memory"]), dev(c["style"])), c["out"], TOL)
+
+
+def make_nets(golden_phases, cfg):
+    from mssrnet_style_transfer_amd import style_generator_builder as B
+    nets = B.build_all(cfg, device="cpu")
+    for k, m in nets.items():
+        m.load_state_dict(golden_phases["init"][k])
+        m.cuda()
+    return nets
+
+
+def gpu_batch(golden_phases):
+    b = golden_phases["batch"]
+    return SimpleNamespace(src=b["src"].cuda(), src_lengths=b["src_lengths"].cuda(), tgt=b["tgt"].cuda(),
+                           labels=b["labels"].cuda())
+
+
+PHASES = [("discriminator", "train_discriminator", ("text_discriminator", "style_discriminator")),
+          ("generator", "train_generator", ("model", "style_generator")),
+          ("reconstruct", "train_reconstruct", ("model", "style_generator")),
+          ("init_launch", "init_launch", ("model", "style_generator"))]
+
+
+@pytest.mark.parametrize("name,fn,trained", PHASES)
+def test_phase_fp32(ops, golden_phases, name, fn, trained):
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    cfg = MSSRConfig.small()
+    nets = make_nets(golden_phases, cfg)
+    tr = Trainer(nets, cfg)
+    c = golden_phases[name]
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    log = getattr(tr, fn)(gpu_batch(golden_phases))
+    for k, v in c["scalars"].items():
+        assert abs(log[k] - v) <= TOL * max(abs(v), 1e-3), (name, k, log[k], v)
+    for n in trained:
+        assert_grads(grads_of(nets[n]), c["grads"][n], 2e-4, name + "." + n)
+        assert_post_step(list(nets[n].named_parameters()), c["post"][n], cfg.learning_rate, name + ".post." + n)
+
+
+@pytest.mark.parametrize("name,fn,trained", PHASES[:3])
+def test_phase_bf16_losses(ops, golden_phases, name, fn, trained):
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    cfg = MSSRConfig.small()
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        nets = make_nets(golden_phases, cfg)
+        tr = Trainer(nets, cfg)
+        c = golden_phases[name]
+        torch.manual_seed(c["seed"])
+        log = getattr(tr, fn)(gpu_batch(golden_phases))
+        for k, v in c["scalars"].items():
+            if k.endswith("_acc") or k.endswith("Wgap") or k.endswith("_cost"):
+                continue            # accuracies are argmax counts; gaps/costs are differences of gains
+            assert abs(log[k] - v) <= 2e-2 * max(abs(v), 1e-2), (name, k, log[k], v)
+        for n in trained:
+            for p in nets[n].parameters():
+                assert p.grad is None or (p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all())
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_soft_decode_and_teacher_step(ops, golden_phases):
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer, teacher_step_loss
+    cfg = MSSRConfig.small()
+    nets = make_nets(golden_phases, cfg)
+    tr = Trainer(nets, cfg)
+    nets["model"].eval()
+    nets["style_generator"].eval()
+    batch = gpu_batch(golden_phases)
+    labels, _, real_src, real_len, _ = tr.unpack_batch(batch)
+    c = golden_phases["decode"]
+    with torch.no_grad():
+        rep = tr._gen_style_represents(1 - labels, real_src, real_len)
+        probs, lens, ids = tr._dynamic_decoding(real_src, real_len, rep, 9)
+    assert_close(rep, c["rep"], TOL)
+    assert_close(probs, c["probs"], TOL)
+    assert torch.equal(ids.cpu(), c["ids"])
+    assert torch.equal(lens.cpu(), c["seq_lens"])
+    t = golden_phases["teacher_step"]
+    teacher = nets["teacher"]
+    teacher.train()
+    for p in teacher.parameters():
+        p.requires_grad_(True)
+    loss, lg = teacher_step_loss(teacher, batch, cfg)
+    assert_close(loss, t["loss"], TOL)
+    assert_close(lg, t["logits"], TOL)
+    loss.backward()
+    assert_grads(grads_of(teacher), t["g"], 2e-4, "teacher")
