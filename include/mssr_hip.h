@@ -83,6 +83,9 @@ typedef struct {
     int out_dtype;   /* dtype of C */
 } mssr_gemm_desc;
 int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
+/* Block tile edge (64 or 32) mssr_gemm picks for an m x n x batch problem; lets a profiler name the
+ * kernel instance (gemm_kernel<.., 64, 64> / <.., 32, 32>) a launch used.  No reference counterpart. */
+int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);
 
 /* --------------------------------------------------------------------- row softmax --------
  * y = softmax(scale * x) along the last axis, optionally masked, optionally log-softmax.

@@ -186,10 +186,14 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+static inline bool use_tile64(int64_t m, int64_t n, int64_t batch) {
+    const int64_t tiles64 = ((m + 63) / 64) * ((n + 63) / 64) * batch;
+    return tiles64 >= 192 && m > 32 && n > 32;
+}
+
 template <typename TI, typename TO>
 static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
-    const int64_t tiles64 = ((a.m + 63) / 64) * ((a.n + 63) / 64) * batch;
-    if (tiles64 >= 192 && a.m > 32 && a.n > 32) {
+    if (use_tile64(a.m, a.n, batch)) {
         dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 63) / 64), (unsigned)batch);
         gemm_kernel<TI, TO, 64, 64><<<grid, dim3(GEMM_THREADS), 0, s>>>(a);
     } else {
@@ -201,6 +205,8 @@ static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
 }  // namespace mssr
 
 using namespace mssr;
+
+extern "C" int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch) { return use_tile64(m, n, batch) ? 64 : 32; }
 
 extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     MSSR_REQUIRE(d, "gemm: null descriptor");

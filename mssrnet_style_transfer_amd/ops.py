@@ -121,8 +121,37 @@ def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, a
     (_, _), (d.c_bo, d.c_bi) = _batch(out)
     d.alpha, d.beta, d.relu = alpha, beta, int(relu)
     d.in_dtype, d.out_dtype = L.dt(a), L.dt(out)
-    L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
+    prof = _state.get("profile")
+    if prof is None:
+        L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
+        return out
+    # bench.py instrumentation: HIP events around this launch, on the stream it is enqueued on
+    lib = L.load()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.mssr_gemm(d, L.stream()), "gemm")
+    e1.record()
+    isz, osz = a.element_size(), out.element_size()
+    nb = bo * bi
+    prof.append(dict(kernel="gemm_kernel<%s,%s,%d>" % ("bf16" if isz == 2 else "f32", "bf16" if osz == 2 else "f32",
+                                                        lib.mssr_gemm_tile(m, n, nb)),
+                     shape=(nb, m, n, k), bytes=nb * ((m * k + k * n) * isz + m * n * osz), flops=2 * nb * m * n * k,
+                     events=(e0, e1)))
     return out
+
+
+def start_profile():
+    """Record (kernel, shape, algorithmic bytes/flops, HIP events) for every GEMM launch."""
+    _state["profile"] = []
+
+
+def stop_profile():
+    rec, _state["profile"] = _state.get("profile") or [], None
+    torch.cuda.synchronize()
+    for r in rec:
+        e0, e1 = r.pop("events")
+        r["ms"] = e0.elapsed_time(e1)
+    return rec
 
 
 class _Matmul(Function):

@@ -141,6 +141,12 @@ class Trainer:
         probs, lens, ids = decode_batch_ori(self.model, self.cfg, real_src, enc_state, mem, real_len, max_dec_steps)
         return probs, torch.tensor(lens, dtype=torch.long, device=real_len.device), ids
 
+    def _arm(self, *modules):
+        """Start overlapping the gradient all-reduce of ``modules`` with their LAST backward."""
+        if self.grad_sync is not None:
+            for m in modules:
+                self.grad_sync.arm(m)
+
     def _finish(self, modules, optims, clip=True):
         if self.grad_sync is not None:
             self.grad_sync(modules)
@@ -176,6 +182,7 @@ class Trainer:
             real_onehot = convert_sent_ids_to_onehot(vocab_target.transpose(0, 1).squeeze(2), cfg.vocab_size)
         t_gp = penalize_gen_text_grad(self._call_text_discriminator, real_onehot, probs_t, text_len, labels_list,
                                       k=cfg.wgan_text_k, lamb=cfg.wgan_text_lamb, gp_norm_seq=cfg.use_gp_norm_seq)
+        self._arm(self.text_discriminator)
         t_gp.backward()
         # style critic
         real_rep_t = self._gen_real_style_represents(real_src, real_len).transpose(0, 1)
@@ -188,6 +195,7 @@ class Trainer:
         s_gp = penalize_gen_style_grad(self._call_style_discriminator, real_rep_t.float(), gen_rep_t.float(),
                                        real_len, labels_list, k=cfg.wgan_style_k, lamb=cfg.wgan_style_lamb,
                                        gp_norm_seq=cfg.use_gp_norm_seq)
+        self._arm(self.style_discriminator)
         s_gp.backward()
         self._finish((self.style_discriminator, self.text_discriminator),
                      (self.style_discriminator_optim, self.text_discriminator_optim))
@@ -213,17 +221,22 @@ class Trainer:
         probs, seq_lens, _ = self._dynamic_decoding(real_src, real_len, rep, max_dec_steps)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
         gain_t = cal_disc_loss(self._call_text_discriminator(probs, lens), desired_list).mean()
+        if not cfg.ap_gen_self_style_text:
+            self._arm(self.model)
         gain_t.backward(self.mone * cfg.text_ap_scale)
         with torch.no_grad():
             acc = self.classifier(probs, lens).argmax(-1).eq(desired).float().mean()
         rep2_t = self._gen_style_represents(desired, real_src, real_len).transpose(0, 1)
         gain_s = cal_disc_loss(self._call_style_discriminator(rep2_t, real_len), desired_list).mean()
+        if not cfg.ap_gen_self_style_text:
+            self._arm(self.style_generator)
         gain_s.backward(self.mone * cfg.style_ap_scale)
         vals = [gain_t, acc, gain_s]
         if cfg.ap_gen_self_style_text:
             rep3 = self._gen_style_represents(labels, real_src, real_len)
             sprobs, _, _ = self._dynamic_decoding(real_src, real_len, rep3, tgt_len)
             vl = self.vocab_loss_from_probs(sprobs, vocab_target.contiguous().view(-1), B)
+            self._arm(self.style_generator, self.model)
             vl.backward()
             vals.append(vl)
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
@@ -275,6 +288,7 @@ class Trainer:
         if not cfg.without_stl_penalty:
             names.append("S_GAP_loss")
             vals.append(l_gap)
+        self._arm(self.style_generator, self.model)
         total.backward()
         # no clipping in this phase; the style generator steps only if it received a loss (:859-863)
         optims = [self.model_optim]
@@ -292,9 +306,11 @@ class Trainer:
         B = len(labels_list)
         real_rep = self._gen_real_style_represents(real_src, real_len)
         l_style = self.cal_style_gap(real_rep, self._gen_style_represents(labels, real_src, real_len), real_len)
+        self._arm(self.style_generator)
         l_style.backward()
         lp = self._self_reconstruct(real_src, real_len, batch.tgt, real_rep)
         l_v = self.vocab_loss(lp.view(-1, lp.size(-1)), vocab_target.contiguous().view(-1), B)
+        self._arm(self.model)
         l_v.backward()
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
         v = torch.stack([l_style.detach(), l_v.detach()]).tolist()

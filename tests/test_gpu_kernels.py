@@ -206,8 +206,7 @@ def test_dropout_mask_replay_and_stats(ops):
     g, = torch.autograd.grad(y.sum(), x, create_graph=True)
     assert_close(g, sel.float() / 0.9, 1e-6)
     assert_close(y[sel], x.detach()[sel] / 0.9, 1e-6)
-    gg, = torch.autograd.grad((g * g).sum(), x, allow_unused=True)     # linear map: no 2nd-order term
-    assert gg is None or float(gg.abs().max()) == 0.0
+    assert not g.requires_grad          # dropout is linear in x: its gradient does not depend on x
     yr = ops.dropout(x, 0.1, True, residual=r).detach()
     dropped = yr == r
     kept_ok = (yr - (x.detach() / 0.9 + r)).abs() <= 1e-6 * (1 + r.abs() + x.detach().abs())
