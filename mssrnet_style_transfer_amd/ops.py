@@ -8,6 +8,7 @@ softmax carry hand-written second-order kernels.  torch is used for memory, view
 autograd book-keeping only; all arithmetic on activations runs in libmssr_hip.so.
 """
 import math
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -44,13 +45,13 @@ def cast(t):
     cd = _state["dtype"]
     if t.dtype == cd:
         return t
-    if t.is_leaf and t.dim() >= 2:
+    if isinstance(t, torch.nn.Parameter):
         key = id(t)
         hit = _cast_cache.get(key)
-        if hit is not None and hit[0] == t._version and hit[1] == t.data_ptr():
-            return hit[2]
+        if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
+            return hit[3]
         c = t.detach().to(cd)
-        _cast_cache[key] = (t._version, t.data_ptr(), c)
+        _cast_cache[key] = (weakref.ref(t), t._version, t.data_ptr(), c)
         return c
     return t.detach().to(cd) if not torch.is_grad_enabled() else t.to(cd)
 

@@ -1,0 +1,77 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/mssr_hip.h declares
+(no compute call is made), the binding fails loudly when the library is absent, and the host-side
+logic (synthetic batch, length rule) agrees with the oracle."""
+import os
+import re
+import ctypes
+
+import pytest
+import torch
+
+from conftest import ROOT
+from mssrnet_style_transfer_amd import _lib
+from mssrnet_style_transfer_amd.config import MSSRConfig
+from mssrnet_style_transfer_amd.synth import make_batch, PAD, BOS, EOS
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "mssr_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mssr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_symbols()
+    assert len(names) >= 18
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), "libmssr_hip.so does not export %s" % n
+        assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
+    assert set(_lib.SIGNATURES) <= set(names)
+    assert _lib.load().mssr_abi_version() == 1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmssr_hip.so")
+    with pytest.raises(RuntimeError, match="no CPU or eager fallback"):
+        _lib.load()
+
+
+def test_cpu_tensors_are_rejected():
+    from mssrnet_style_transfer_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        ops.layer_norm(torch.randn(4, 8), torch.ones(8), torch.zeros(8))
+
+
+def test_synthetic_batch_layout():
+    b = make_batch(80, 16, 9606, seed=123)
+    assert b.src.shape == (17, 80, 1) and b.tgt.shape == (18, 80, 1)
+    lens = b.src_lengths - 1
+    assert int(lens.max()) == 16 and int(lens.min()) >= 3
+    assert torch.equal(lens, torch.sort(lens, descending=True)[0])
+    assert bool((b.tgt[0] == BOS).all())
+    for i in range(80):
+        n = int(lens[i])
+        assert int(b.tgt[n + 1, i, 0]) == EOS and bool((b.tgt[n + 2:, i, 0] == PAD).all())
+        assert bool((b.src[1:n + 1, i, 0] >= 9).all()) and bool((b.src[n + 1:, i, 0] == PAD).all())
+        assert int(b.src[0, i, 0]) - 4 == int(b.labels[i])
+    assert b.n_tokens == int((lens + 1).sum())
+    assert torch.equal(make_batch(80, 16, 9606, seed=123).src, b.src)
+
+
+def test_length_rule_matches_oracle():
+    from mssrnet_style_transfer_amd.train_and_translate import fetch_dec_output_length
+    from oracle.phases import fetch_dec_output_length as oracle_rule
+    cfg = MSSRConfig.small()
+    torch.manual_seed(0)
+    for trial in range(20):
+        probs = torch.rand(9, 7, 20)
+        probs[..., cfg.eos_idx] += (torch.rand(9, 7) > 0.7).float()
+        probs[..., cfg.dot_idx] += (torch.rand(9, 7) > 0.8).float()
+        for aware in (True, False):
+            c = cfg.with_(sent_stop_aware=aware)
+            a, ia = fetch_dec_output_length(probs, c)
+            b, ib = oracle_rule(probs, c)
+            assert a == b and torch.equal(ia, ib)
+            assert max(a) == 9

@@ -1,0 +1,77 @@
+"""world_size-2 gloo test of the data-parallel gradient reduction (parallel.GradSync): reduced
+grad == (sum over ranks) / world, for the plain path, the overlapped (armed) path, several
+accumulating backwards before one reduction, and parameters that received no gradient."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _net():
+    torch.manual_seed(5)
+    return nn.Sequential(nn.Linear(16, 32), nn.ReLU(), nn.Linear(32, 32), nn.ReLU(), nn.Linear(32, 4),
+                         nn.Linear(4, 4))        # last layer stays unused -> no grad
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mssrnet_style_transfer_amd.parallel import GradSync
+    res = {}
+    for mode in ("plain", "armed"):
+        net = _net()
+        sync = GradSync(world, bucket_bytes=2048)      # tiny buckets -> several collectives
+        torch.manual_seed(100 + rank)
+        x1, x2 = torch.randn(8, 16), torch.randn(8, 16)
+        body = net[:5]
+        body(x1).pow(2).sum().backward()               # first backward accumulates locally
+        if mode == "armed":
+            sync.arm(net)
+        body(x2).sum().backward()                      # last backward (overlapped when armed)
+        local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        sync([net])
+        res[mode] = (local, [None if p.grad is None else p.grad.clone() for p in net.parameters()])
+    torch.save(res, os.path.join(out, "rank%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_grad_sync_two_ranks(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r = [torch.load(os.path.join(str(tmp_path), "rank%d.pt" % i), weights_only=True) for i in range(world)]
+    for mode in ("plain", "armed"):
+        n = len(r[0][mode][0])
+        for i in range(n):
+            locs = [r[k][mode][0][i] for k in range(world)]
+            if locs[0] is None:
+                for k in range(world):      # never received a gradient: reduced value is zero
+                    g = r[k][mode][1][i]
+                    assert g is None or float(g.abs().max()) == 0.0
+                continue
+            want = sum(locs) / world
+            for k in range(world):
+                assert torch.allclose(r[k][mode][1][i], want, rtol=1e-6, atol=1e-7), (mode, i, k)
+
+
+def test_single_rank_is_a_noop():
+    from mssrnet_style_transfer_amd.parallel import GradSync
+    net = _net()
+    net[:5](torch.randn(3, 16)).sum().backward()
+    before = [p.grad.clone() for p in net[:5].parameters()]
+    s = GradSync(1)
+    s.arm(net)
+    s([net])
+    for a, p in zip(before, net[:5].parameters()):
+        assert torch.equal(a, p.grad)
