@@ -81,11 +81,25 @@ typedef struct {
     int relu;
     int in_dtype;    /* dtype of A, B, residual, gate */
     int out_dtype;   /* dtype of C */
+    /* dropout fused into the epilogue (after ReLU, before the residual): drop_p in [0,1), 0 = off;
+     * keep(row,col) = hash(drop_seed, z*m*n + row*n + col) >= drop_p * 2^32 -- the same counter-based
+     * hash as mssr_dropout_fwd, so a backward pass can regenerate the mask from the seed. */
+    float drop_p;
+    uint64_t drop_seed;
+    /* optional fp32 scratch for the split-K slabs of the skinny-M kernel (m <= 128, k > 1024):
+     * ceil(k/1024) * m * n floats.  NULL: such problems use the general kernel. */
+    void* workspace;
+    int64_t workspace_bytes;
+    int no_skinny;   /* 1 = always use the general tiled kernel */
 } mssr_gemm_desc;
 int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
 /* Block tile edge (64 or 32) mssr_gemm picks for an m x n x batch problem; lets a profiler name the
  * kernel instance (gemm_kernel<.., 64, 64> / <.., 32, 32>) a launch used.  No reference counterpart. */
 int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);
+/* 1 when mssr_gemm would route `desc` to the skinny-M kernel (m <= 128, bf16, both operands
+ * k-contiguous and 16-byte aligned, k a multiple of 32): C = A[m,k] . W[n,k]^T with the block's four
+ * waves splitting K and loading straight into MFMA fragments.  No reference counterpart. */
+int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
 
 /* --------------------------------------------------------------------- row softmax --------
  * y = softmax(scale * x) along the last axis, optionally masked, optionally log-softmax.

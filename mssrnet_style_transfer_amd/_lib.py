@@ -26,7 +26,9 @@ class GemmDesc(Structure):
                 ("a_bo", c_int64), ("a_bi", c_int64), ("b_bo", c_int64), ("b_bi", c_int64),
                 ("c_bo", c_int64), ("c_bi", c_int64),
                 ("alpha", c_float), ("beta", c_float), ("relu", c_int),
-                ("in_dtype", c_int), ("out_dtype", c_int)]
+                ("in_dtype", c_int), ("out_dtype", c_int),
+                ("drop_p", c_float), ("drop_seed", c_uint64),
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("no_skinny", c_int)]
 
 
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
@@ -39,6 +41,7 @@ SIGNATURES = {
     "mssr_layernorm_bwd_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
     "mssr_gemm": ([POINTER(GemmDesc), _P], c_int),
     "mssr_gemm_tile": ([_L, _L, _L], c_int),
+    "mssr_gemm_is_skinny": ([POINTER(GemmDesc)], c_int),
     "mssr_softmax_fwd": ([_P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _I, _P], c_int),
     "mssr_softmax_bwd": ([_P, _P, _P, _L, _I, _L, _L, _L, _F, _I, _I, _I, _I, _P], c_int),
     "mssr_softmax_bwd_bwd": ([_P, _P, _P, _P, _L, _I, _L, _F, _I, _P], c_int),

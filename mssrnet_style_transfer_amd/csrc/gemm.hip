@@ -6,7 +6,7 @@
 // the next K-tile is fetched into registers while the current one feeds the MFMAs.
 // Operands may be k-contiguous ("NT" weights, activations) or row-contiguous (transposed
 // views: dW = dY^T X, P V, ...): the loader picks the coalesced direction per operand.
-#include "common.hpp"
+#include "gemm_common.hpp"
 
 namespace mssr {
 
@@ -35,22 +35,6 @@ template <> struct Mma<float> {
     static __device__ __forceinline__ f32x4 mma(Frag a, Frag b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
     }
-};
-
-struct GemmArgs {
-    const void* a;
-    const void* b;
-    void* c;
-    const float* bias;
-    const void* residual;
-    const void* gate;
-    int64_t m, n, k;
-    int64_t a_rs, a_cs, b_rs, b_cs, ldc, ldr, ldg;
-    int64_t batch_inner;
-    int64_t a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;
-    float alpha, beta;
-    int relu;
-    int a_vec, b_vec;   // 16-B vector loads allowed for this operand
 };
 
 // One operand tile [ROWS][BK] of a matrix addressed as elem(r, k) = src[r*rs + k*cs].
@@ -175,12 +159,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
                 if (row >= p.m) continue;
-                float v = p.alpha * acc[i][j][r] + bias;
-                if (p.relu) v = fmaxf(v, 0.f);
-                if (R) v += to_f(R[row * p.ldr + col]);
-                if (G) v = to_f(G[row * p.ldg + col]) > 0.f ? v : 0.f;
-                if (p.beta != 0.f) v += p.beta * to_f(C[row * p.ldc + col]);
-                C[row * p.ldc + col] = from_f<TO>(v);
+                epilogue_store<TI, TO>(p, acc[i][j][r], row, col, bias, C, R, G, (int64_t)blockIdx.z * p.m * p.n);
             }
         }
     }
@@ -207,6 +186,19 @@ static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
 using namespace mssr;
 
 extern "C" int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch) { return use_tile64(m, n, batch) ? 64 : 32; }
+
+// 1 when mssr_gemm routes this problem to the skinny-M kernel (same eligibility test, no launch)
+extern "C" int mssr_gemm_is_skinny(const mssr_gemm_desc* d) {
+    if (!d || d->no_skinny || d->in_dtype != MSSR_BF16 || d->batch_outer * d->batch_inner != 1) return 0;
+    if (d->m < 1 || d->m > 128 || d->k < 32 || d->k % 32 != 0 || d->beta != 0.f) return 0;
+    if (d->a_cs != 1 || d->b_rs != 1 || d->a_rs % 8 != 0 || d->b_cs % 8 != 0) return 0;
+    if (!aligned(d->a, 16) || !aligned(d->b, 16)) return 0;
+    if (d->k > 1024) {
+        const int64_t need = ((d->k / 32 + 31) / 32) * d->m * d->n * (int64_t)sizeof(float);
+        if (!d->workspace || d->workspace_bytes < need || !aligned(d->workspace, 16)) return 0;
+    }
+    return 1;
+}
 
 extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     MSSR_REQUIRE(d, "gemm: null descriptor");
@@ -235,6 +227,14 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     a.batch_inner = d->batch_inner;
     a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
+    MSSR_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of [0,1)", d->drop_p);
+    a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    a.ksplit = 1;
+    a.partial = nullptr;
+    if (d->workspace && d->m <= 128 && d->k > 1024) {
+        const int64_t need = ((d->k / 32 + 31) / 32) * d->m * d->n * (int64_t)sizeof(float);
+        if (d->workspace_bytes >= need && aligned(d->workspace, 16)) a.partial = (float*)d->workspace;
+    }
     const int ch = 16 / (int)dsize(d->in_dtype);
     // 16-B vector loads need: base aligned, the non-unit stride and batch strides multiples of the chunk
     const int64_t a_ld = d->a_cs == 1 ? d->a_rs : d->a_cs;
@@ -242,6 +242,7 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     a.a_vec = aligned(d->a, 16) && a_ld % ch == 0 && d->a_bo % ch == 0 && d->a_bi % ch == 0;
     a.b_vec = aligned(d->b, 16) && b_ld % ch == 0 && d->b_bo % ch == 0 && d->b_bi % ch == 0;
     hipStream_t s = (hipStream_t)stream;
+    if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) { MSSR_LAUNCH_OK("gemm(skinny)"); }
     if (d->in_dtype == MSSR_F32) launch<float, float>(a, batch, s);
     else if (d->out_dtype == MSSR_BF16) launch<bf16, bf16>(a, batch, s);
     else launch<bf16, float>(a, batch, s);

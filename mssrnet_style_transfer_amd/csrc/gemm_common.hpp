@@ -1,0 +1,48 @@
+// Shared GEMM argument block and epilogue (gemm.hip: general tiled kernel; gemm_skinny.hip: M <= 128).
+#pragma once
+#include "common.hpp"
+
+namespace mssr {
+
+struct GemmArgs {
+    const void* a;
+    const void* b;
+    void* c;
+    const float* bias;
+    const void* residual;
+    const void* gate;
+    int64_t m, n, k;
+    int64_t a_rs, a_cs, b_rs, b_cs, ldc, ldr, ldg;
+    int64_t batch_inner;
+    int64_t a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;
+    float alpha, beta;
+    int relu;
+    int a_vec, b_vec;   // 16-B vector loads allowed for this operand
+    float drop_p;       // > 0: dropout in the epilogue, keep = hash(seed, z*m*n + row*n + col) >= p*2^32
+    uint64_t drop_seed;
+    float* partial;     // skinny split-K: fp32 slabs [ksplit][m][n]
+    int ksplit;
+};
+
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
+    return hash_u32(seed, idx) >= (uint32_t)((double)p * 4294967296.0);
+}
+
+// v = alpha*acc (+bias) ; relu ; dropout ; (+residual) ; gate ; (+beta*C_old)
+template <typename TI, typename TO>
+__device__ __forceinline__ void epilogue_store(const GemmArgs& p, float acc, int64_t row, int64_t col, float bias,
+                                               TO* C, const TI* R, const TI* G, int64_t zoff) {
+    float v = p.alpha * acc + bias;
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.drop_p > 0.f)
+        v = drop_keep(p.drop_seed, (uint64_t)(zoff + row * p.n + col), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+    if (R) v += to_f(R[row * p.ldr + col]);
+    if (G) v = to_f(G[row * p.ldg + col]) > 0.f ? v : 0.f;
+    if (p.beta != 0.f) v += p.beta * to_f(C[row * p.ldc + col]);
+    C[row * p.ldc + col] = from_f<TO>(v);
+}
+
+// returns true when the skinny path took the problem (gemm_skinny.hip)
+bool gemm_skinny_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
+
+}  // namespace mssr

@@ -85,7 +85,17 @@ def _batch(t):
     raise ValueError("matmul supports at most two batch dimensions")
 
 
-def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, alpha=1.0, out=None, beta=0.0):
+def _workspace(device):
+    """Persistent fp32 scratch for the split-K slabs of the skinny-M GEMM (one per device)."""
+    ws = _state.setdefault("ws", {})
+    t = ws.get(device)
+    if t is None:
+        t = ws[device] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+    return t
+
+
+def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, alpha=1.0, out=None, beta=0.0,
+         drop_p=0.0, drop_seed=0, no_skinny=False):
     """out[..., M, N] = epilogue(alpha * a[..., M, K] @ (b[..., N, K]^T if tb else b[..., K, N]))."""
     L.require_cuda(a, b)
     a, a_rs, a_cs = _mat(a)
@@ -122,6 +132,10 @@ def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, a
     (_, _), (d.c_bo, d.c_bi) = _batch(out)
     d.alpha, d.beta, d.relu = alpha, beta, int(relu)
     d.in_dtype, d.out_dtype = L.dt(a), L.dt(out)
+    d.drop_p, d.drop_seed, d.no_skinny = drop_p, drop_seed, int(no_skinny)
+    if m <= 128 and k > 1024:
+        ws = _workspace(a.device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     prof = _state.get("profile")
     if prof is None:
         L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
@@ -134,8 +148,11 @@ def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, a
     e1.record()
     isz, osz = a.element_size(), out.element_size()
     nb = bo * bi
-    prof.append(dict(kernel="gemm_kernel<%s,%s,%d>" % ("bf16" if isz == 2 else "f32", "bf16" if osz == 2 else "f32",
-                                                        lib.mssr_gemm_tile(m, n, nb)),
+    kname = ("gemm_skinny_kernel<%d,%s>" % ((m + 15) // 16, "bf16" if osz == 2 else "f32")
+             if lib.mssr_gemm_is_skinny(d) else
+             "gemm_kernel<%s,%s,%d>" % ("bf16" if isz == 2 else "f32", "bf16" if osz == 2 else "f32",
+                                        lib.mssr_gemm_tile(m, n, nb)))
+    prof.append(dict(kernel=kname,
                      shape=(nb, m, n, k), bytes=nb * ((m * k + k * n) * isz + m * n * osz), flops=2 * nb * m * n * k,
                      events=(e0, e1)))
     return out

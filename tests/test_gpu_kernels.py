@@ -412,3 +412,33 @@ def test_decoder_golden(ops, golden_modules):
     with torch.no_grad():
         ids = torch.cat([dec(dev(c["tgt"])[s:s + 1], memory, memory_lengths=lens, step=s)[0] for s in range(4)], 0)
     assert_close(ids, c["id_step_outs"], TOL32)
+
+
+@pytest.mark.parametrize("M,N,K", [(80, 512, 512), (1, 512, 64), (16, 1536, 512), (128, 9606, 512), (80, 512, 9632),
+                                   (77, 130, 1024), (80, 1024, 2048)])
+def test_gemm_skinny_path(ops, M, N, K):
+    """The M <= 128 weight-streaming kernel (gemm_skinny.hip) against fp64 and against the general
+    tiled kernel, including split-K (K > 1024) and every epilogue feature."""
+    from mssrnet_style_transfer_amd import _lib
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K).bfloat16()
+    w = torch.randn(N, K).bfloat16()
+    ref = a.double() @ w.double().t()
+    ac, wc = a.cuda(), w.cuda()
+    out = ops.gemm(ac, wc, True, torch.bfloat16)
+    assert_close(out.float(), ref, 1e-2, "skinny")
+    out32 = ops.gemm(ac, wc, True, torch.float32)
+    assert_close(out32, ref, 2e-5 * math.sqrt(K), "skinny f32 out")
+    bias = torch.randn(N).cuda()
+    res = torch.randn(M, N).bfloat16().cuda()
+    gate = torch.randn(M, N).bfloat16().cuda()
+    kw = dict(bias=bias, relu=True, residual=res, gate=gate, alpha=0.5, drop_p=0.25, drop_seed=99)
+    o1 = ops.gemm(ac, wc, True, torch.float32, **kw)
+    o2 = ops.gemm(ac, wc, True, torch.float32, no_skinny=True, **kw)
+    assert torch.equal(o1 == 0, o2 == 0)                    # same keep mask / gate pattern
+    assert_close(o1, o2, 1e-4, "skinny vs tiled epilogue")
+    kept = ops.gemm(ac, wc, True, torch.float32, drop_p=0.25, drop_seed=5)
+    frac = (kept != 0).float().mean().item()
+    assert abs(frac - 0.75) < 0.05 or M * N < 2000
+    sel = kept != 0
+    assert_close(kept[sel], (out32 / 0.75)[sel], 1e-5, "dropout scaling")
