@@ -155,6 +155,84 @@ int mssr_embedding_bwd(const void* dout, const int64_t* ids, float* dweight, int
 int mssr_scale_add_pe(const void* x, const float* pe, void* out, int64_t rows, int d, int64_t batch,
                       int step, float scale, int dtype, void* stream);
 
+/* ------------------------------------------------- step-wise soft-decode engine -----------
+ * Replaces the Python loop of the reference's differentiable decoding,
+ * TrainTranslator.decode_batch_ori (onmt/train_and_translate.py:202-231) ->
+ * TransformerDecoder.forward(step=s) (onmt/decoders/transformer.py:289-337) -> n_layers x
+ * TransformerDecoderLayer._forward (:110-171) with the layer_cache protocol of
+ * onmt/modules/multi_headed_attn.py:133-160 -> generator Linear + softmax(/T)
+ * (onmt/train_and_translate.py:95-116), and the autograd backward of that loop.
+ * One call enqueues one decode step (or all of them) for the whole batch; the caller owns
+ * every buffer (nothing is allocated here).  Weights are in the compute dtype, nn.Linear layout
+ * [out,in] (w_*) plus a transposed copy [in,out] (wt_*, backward only); biases and LayerNorm
+ * parameters are float.  `layers` is a HOST array. */
+typedef struct {
+    const void *w_qkv, *wt_qkv;   /* self attention query|keys|values rows packed [3d,d]; wt [d,3d] */
+    const void *w_so, *wt_so;     /* self attention final_linear [d,d] */
+    const void *w_cq, *wt_cq;     /* context attention linear_query [d,d] */
+    const void *w_co, *wt_co;     /* context attention final_linear [d,d] */
+    const void *w_1, *wt_1;       /* feed_forward.w_1 [ff,d]; wt [d,ff] */
+    const void *w_2, *wt_2;       /* feed_forward.w_2 [d,ff]; wt [ff,d] */
+    const float *b_qkv, *b_so, *b_cq, *b_co, *b_1, *b_2;
+    const float *ln1_g, *ln1_b;   /* layer_norm_1 */
+    const float *ln2_g, *ln2_b;   /* layer_norm_2 */
+    const float *lnf_g, *lnf_b;   /* feed_forward.layer_norm */
+} mssr_dec_layer;
+
+typedef struct {
+    int dtype;                    /* compute dtype of weights / activations */
+    int B, d, heads, ff, n_layers;
+    int V, Vp;                    /* vocabulary and its padding to a multiple of 32 */
+    int Ls, T;                    /* source (memory) length, number of decode steps */
+    int save;                     /* 1: keep per-step activations for mssr_decode_step_bwd */
+    int training;                 /* 1: dropout active (p_drop residual/FFN/embedding, p_attn attention) */
+    float p_drop, p_attn, temperature;
+    uint64_t seed;
+    const mssr_dec_layer* layers; /* host array [n_layers] */
+    const void* emb_t;            /* decoder embedding table transposed [d, Vp] (padded columns zero) */
+    const void* emb;              /* the table itself [V, d] (backward) */
+    const float* pe;              /* positional table [>= T, d] */
+    const void* w_gen;            /* generator Linear [V, d] */
+    const void* wt_gen;           /* its transpose [d, Vp], padded columns zero (backward) */
+    const float* b_gen;
+    const float *lnF_g, *lnF_b;   /* decoder.layer_norm */
+    const void* mem_kv;           /* [B, Ls, n_layers, 2d]: context keys|values of the memory bank, all layers */
+    const uint8_t* src_mask;      /* [B, Ls], nonzero = source padding */
+    void* in_all;                 /* [T+1][B, Vp] step inputs; slot 0 = one-hot <s>; padded columns zero */
+    float* probs;                 /* [T][B, V] output probabilities (float) */
+    void* X;                      /* [n_layers+1][Ts][B, d]   (Ts = save ? T : 1) */
+    void* qkv;                    /* [n_layers][T][B, 3d]     self-attention projections = K/V cache */
+    void* actD;                   /* [n_layers][8][Ts][B, d]  n1|ctx1|h1|n2|qc|ctx2|h2|n3 */
+    void* actF;                   /* [n_layers][Ts][B, ff] */
+    float* stats;                 /* [3*n_layers+1][2][Ts][B] LayerNorm mean, rstd */
+    void* nf;                     /* [Ts][B, d] */
+    void* logits;                 /* [B, Vp] */
+    void* tmp;                    /* [B, d] */
+    void* gemm_ws;                /* split-K scratch of mssr_gemm (see mssr_gemm_desc.workspace) */
+    int64_t gemm_ws_bytes;
+    /* backward only (NULL for forward-only plans) */
+    float* dprobs;                /* [T][B, V] in: dL/dprobs; the feedback path accumulates into it */
+    void* dlogits;                /* [T][B, Vp], padded columns zero */
+    void* dX;                     /* [B, d] */
+    void* dqkv;                   /* [n_layers][T][B, 3d] */
+    void* dactD;                  /* [n_layers][7][T][B, d]  dn1|d_so|dn2|d_cq|d_co|dn3|d_f2 */
+    void* dactF;                  /* [n_layers][T][B, ff]    d_f1 */
+    float* dkv_acc;               /* [n_layers][T][B, 2d] zeroed by the caller */
+    float* dmem_acc;              /* [B, Ls, n_layers, 2d] zeroed by the caller: dL/d mem_kv */
+    void* d_e;                    /* [T][B, d] gradient of the soft-embedding product */
+    void* dnf;                    /* [T][B, d] */
+} mssr_decode_plan;
+/* One decode step: embeds in_all[step], runs the layers with the cache rows 0..step, writes
+ * probs[step] and in_all[step+1]. */
+int mssr_decode_step_fwd(const mssr_decode_plan* plan, int step, void* stream);
+/* Its backward; call for step = T-1 .. 0.  Leaves the gradient of every GEMM output in the d*
+ * slabs (the caller contracts them with the saved activations into parameter gradients, one
+ * product per parameter over all steps) and dL/d mem_kv in dmem_acc. */
+int mssr_decode_step_bwd(const mssr_decode_plan* plan, int step, void* stream);
+/* All steps in one call. */
+int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);
+int mssr_decode_bwd(const mssr_decode_plan* plan, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -31,6 +31,28 @@ class GemmDesc(Structure):
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("no_skinny", c_int)]
 
 
+class DecLayer(Structure):
+    """mssr_dec_layer (include/mssr_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2", "wt_2",
+        "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2",
+        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "lnf_g", "lnf_b")]
+
+
+class DecodePlan(Structure):
+    """mssr_decode_plan (include/mssr_hip.h)."""
+    _fields_ = ([(n, c_int) for n in ("dtype", "B", "d", "heads", "ff", "n_layers", "V", "Vp", "Ls", "T", "save",
+                                      "training")]
+                + [("p_drop", c_float), ("p_attn", c_float), ("temperature", c_float), ("seed", c_uint64),
+                   ("layers", POINTER(DecLayer))]
+                + [(n, c_void_p) for n in ("emb_t", "emb", "pe", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b",
+                                           "mem_kv", "src_mask", "in_all", "probs", "X", "qkv", "actD", "actF",
+                                           "stats", "nf", "logits", "tmp", "gemm_ws")]
+                + [("gemm_ws_bytes", c_int64)]
+                + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dkv_acc",
+                                           "dmem_acc", "d_e", "dnf")])
+
+
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
 SIGNATURES = {
     "mssr_abi_version": ([], c_int),
@@ -53,6 +75,10 @@ SIGNATURES = {
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
     "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),
+    "mssr_decode_step_fwd": ([POINTER(DecodePlan), _I, _P], c_int),
+    "mssr_decode_step_bwd": ([POINTER(DecodePlan), _I, _P], c_int),
+    "mssr_decode_fwd": ([POINTER(DecodePlan), _P], c_int),
+    "mssr_decode_bwd": ([POINTER(DecodePlan), _P], c_int),
 }
 
 _lib = None

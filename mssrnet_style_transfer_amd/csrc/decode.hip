@@ -1,0 +1,634 @@
+// Step-wise soft-decode engine: one C call runs ONE decode step through all decoder layers
+// (forward), or its exact reverse (backward), launching every kernel back to back on the stream.
+//
+// Replaces the Python loop of the reference's differentiable decoding
+// (onmt/train_and_translate.py:202-231 -> TransformerDecoder.forward with step=s,
+// onmt/decoders/transformer.py:289-337 -> 12 x TransformerDecoderLayer._forward :110-171 with
+// the layer_cache protocol of onmt/modules/multi_headed_attn.py:133-160 -> generator Linear +
+// softmax, :95-116).  All per-step tensors live in step-major slabs [T][B, width] that the
+// caller allocates once (mssr_decode_plan); the K/V "cache" is the packed projection slab
+// qkv[l] = [T][B, 3d] itself, so nothing is concatenated or copied as the sequence grows.
+// Weight / bias / LayerNorm gradients are NOT formed per step: the backward stores the
+// gradient of every GEMM output in a slab and the caller contracts each slab once at the end
+// (dW = dY_all^T X_all with a long reduction dimension instead of 28 products of depth 80).
+#include "common.hpp"
+
+namespace mssr {
+
+constexpr int AT_MAXK = 512;    // keys per (b, h) the step-attention kernels handle
+
+// ------------------------------------------------------------------ single-query attention
+// One wave64 per (batch, head).  q [dh], keys/values addressed with strides, optional pad mask.
+// ctx = dropout(softmax(scale * q.K^T (masked))) . V
+template <typename T>
+__global__ __launch_bounds__(256) void attn_step_fwd_kernel(
+    const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
+    int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
+    int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    __shared__ float sc[4][AT_MAXK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh_raw = blockIdx.x * 4 + wave;
+    const bool active = bh_raw < B * H;
+    const int bh = active ? bh_raw : B * H - 1;     // idle waves shadow the last slice and store nothing
+    const int b = bh / H, h = bh % H;
+    const T* qp = q + (int64_t)b * q_bs + h * dh;
+    const T* kp = k + (int64_t)b * kv_bs + h * dh;
+    const T* vp = v + (int64_t)b * kv_bs + h * dh;
+    float* s = sc[wave];
+    // scores: lane <-> key
+    float mx = -INFINITY;
+    for (int t = lane; t < Lk; t += 64) {
+        const T* kr = kp + (int64_t)t * kv_ts;
+        float a = 0.f;
+        for (int j = 0; j < dh; j += 4) {
+            float kq[4], qq[4];
+            V4<T>::load(kr + j, kq);
+            V4<T>::load(qp + j, qq);
+            a += kq[0] * qq[0] + kq[1] * qq[1] + kq[2] * qq[2] + kq[3] * qq[3];
+        }
+        a *= scale;
+        if (mask && mask[(int64_t)b * mask_bs + t]) a = -1e18f;
+        s[t] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Lk; t += 64) {
+        const float e = expf(s[t] - mx);
+        s[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    for (int t = lane; t < Lk; t += 64) {
+        float p = s[t] * inv;
+        if (p_drop > 0.f) p = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? p * keep_scale : 0.f;
+        s[t] = p;
+    }
+    __syncthreads();
+    if (!active) return;
+    // context: lane <-> feature
+    for (int j = lane; j < dh; j += 64) {
+        float a = 0.f;
+        for (int t = 0; t < Lk; ++t) a += s[t] * to_f(vp[(int64_t)t * kv_ts + j]);
+        ctx[(int64_t)b * ctx_bs + h * dh + j] = from_f<T>(a);
+    }
+}
+
+// Backward of the above for one step.  Recomputes the probabilities (fp32) from q and K, then
+//   dp = dctx.V^T (x dropout) ; ds = p (dp - sum p dp) scale ; dq = ds.K ;
+//   dK_acc[t] += ds_t q ; dV_acc[t] += pd_t dctx      (fp32 accumulators, one wave owns its (b,h) slice)
+// If fin_row >= 0 the accumulated row `fin_row` of dK/dV is final (no later step touches it) and is
+// written in the storage dtype to dk_out/dv_out (the slot of the packed dqkv slab for that step).
+template <typename T>
+__global__ __launch_bounds__(256) void attn_step_bwd_kernel(
+    const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
+    int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
+    T* __restrict__ dq, int64_t dq_bs, float* __restrict__ dk_acc, float* __restrict__ dv_acc, int64_t acc_bs,
+    int64_t acc_ts, int fin_row, T* __restrict__ dk_out, T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh,
+    int Lk, float scale, float p_drop, uint64_t seed) {
+    __shared__ float s_p[4][AT_MAXK];      // p, then ds
+    __shared__ float s_pd[4][AT_MAXK];     // dropped p (what multiplied V in the forward)
+    __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh_raw = blockIdx.x * 4 + wave;
+    const bool active = bh_raw < B * H;
+    const int bh = active ? bh_raw : B * H - 1;     // idle waves shadow the last slice and store nothing
+    const int b = bh / H, h = bh % H;
+    const T* qp = q + (int64_t)b * q_bs + h * dh;
+    const T* kp = k + (int64_t)b * kv_bs + h * dh;
+    const T* vp = v + (int64_t)b * kv_bs + h * dh;
+    const T* dcp = dctx + (int64_t)b * dctx_bs + h * dh;
+    float* s = s_p[wave];
+    float* pd = s_pd[wave];
+    float* dpv = s_dp[wave];
+    float mx = -INFINITY;
+    for (int t = lane; t < Lk; t += 64) {
+        const T* kr = kp + (int64_t)t * kv_ts;
+        float a = 0.f;
+        for (int j = 0; j < dh; j += 4) {
+            float kq[4], qq[4];
+            V4<T>::load(kr + j, kq);
+            V4<T>::load(qp + j, qq);
+            a += kq[0] * qq[0] + kq[1] * qq[1] + kq[2] * qq[2] + kq[3] * qq[3];
+        }
+        a *= scale;
+        if (mask && mask[(int64_t)b * mask_bs + t]) a = -1e18f;
+        s[t] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Lk; t += 64) {
+        const float e = expf(s[t] - mx);
+        s[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    // dp_t = m_t * sum_j dctx_j V[t][j] ; r = sum_t p_t dp_t
+    float r = 0.f;
+    for (int t = lane; t < Lk; t += 64) {
+        const float p = s[t] * inv;
+        float m = 1.0f;
+        if (p_drop > 0.f) m = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? keep_scale : 0.f;
+        const T* vr = vp + (int64_t)t * kv_ts;
+        float a = 0.f;
+        for (int j = 0; j < dh; j += 4) {
+            float vv[4], dd[4];
+            V4<T>::load(vr + j, vv);
+            V4<T>::load(dcp + j, dd);
+            a += vv[0] * dd[0] + vv[1] * dd[1] + vv[2] * dd[2] + vv[3] * dd[3];
+        }
+        const float dp = a * m;
+        s[t] = p;
+        pd[t] = p * m;
+        dpv[t] = dp;
+        r += p * dp;
+    }
+    r = wave_sum(r);
+    for (int t = lane; t < Lk; t += 64) {
+        float ds = s[t] * (dpv[t] - r) * scale;
+        if (mask && mask[(int64_t)b * mask_bs + t]) ds = 0.f;     // masked_fill: no gradient to the score
+        s[t] = ds;
+    }
+    __syncthreads();
+    if (!active) return;
+    // lane <-> feature: dq, dK, dV
+    for (int j = lane; j < dh; j += 64) {
+        const float qj = to_f(qp[j]);
+        const float dcj = to_f(dcp[j]);
+        float a = 0.f;
+        float* dkp = dk_acc + (int64_t)b * acc_bs + h * dh + j;
+        float* dvp = dv_acc + (int64_t)b * acc_bs + h * dh + j;
+        for (int t = 0; t < Lk; ++t) {
+            const float ds = s[t];
+            a += ds * to_f(kp[(int64_t)t * kv_ts + j]);
+            const float nk = dkp[(int64_t)t * acc_ts] + ds * qj;
+            const float nv = dvp[(int64_t)t * acc_ts] + pd[t] * dcj;
+            dkp[(int64_t)t * acc_ts] = nk;
+            dvp[(int64_t)t * acc_ts] = nv;
+            if (t == fin_row) {
+                dk_out[(int64_t)b * out_bs + h * dh + j] = from_f<T>(nk);
+                dv_out[(int64_t)b * out_bs + h * dh + j] = from_f<T>(nv);
+            }
+        }
+        dq[(int64_t)b * dq_bs + h * dh + j] = from_f<T>(a);
+    }
+}
+
+// dx = dres + rstd * (a - mean(a) - xhat * mean(a * xhat)), a = gamma * dy   (no parameter gradients:
+// those are contracted once over all steps by the caller)
+template <typename T>
+__global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, const T* __restrict__ dres,
+                                                        T* __restrict__ dx, int rows, int d) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const float mu = mean[row], rs = rstd[row];
+    const T* xr = x + (int64_t)row * d;
+    const T* dr = dy + (int64_t)row * d;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane * 4; c < d; c += 256) {
+        float xv[4], dv[4], g[4];
+        V4<T>::load(xr + c, xv);
+        V4<T>::load(dr + c, dv);
+        V4<float>::load(gamma + c, g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = dv[j] * g[j];
+            s1 += a;
+            s2 += a * (xv[j] - mu) * rs;
+        }
+    }
+    const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+    for (int c = lane * 4; c < d; c += 256) {
+        float xv[4], dv[4], g[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        V4<T>::load(xr + c, xv);
+        V4<T>::load(dr + c, dv);
+        V4<float>::load(gamma + c, g);
+        if (dres) V4<T>::load(dres + (int64_t)row * d + c, rr);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rr[j] + rs * (dv[j] * g[j] - c1 - (xv[j] - mu) * rs * c2);
+        V4<T>::store(dx + (int64_t)row * d + c, o);
+    }
+}
+
+// y = x * keep(seed, i) / (1 - p) * extra   (dropout forward-replay / backward from the seed alone)
+template <typename T>
+__global__ __launch_bounds__(256) void drop_replay_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n,
+                                                          float p, uint64_t seed, float extra) {
+    const float sc = extra / (1.0f - p);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        float v[4], o[4];
+        V4<T>::load(x + i, v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = hash_u32(seed, (uint64_t)(i + j)) >= thr ? v[j] * sc : 0.f;
+        V4<T>::store(y + i, o);
+    }
+}
+
+// x0 = dropout(e * s + pe[step])   (Embeddings soft path epilogue, onmt/modules/embeddings.py:48-53)
+template <typename T>
+__global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict__ e, const float* __restrict__ pe,
+                                                             T* __restrict__ out, int rows, int d, int step, float s,
+                                                             float p, uint64_t seed) {
+    const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const int64_t n = (int64_t)rows * d;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        const int c = (int)(i % d);
+        float v[4], pp[4], o[4];
+        V4<T>::load(e + i, v);
+        V4<float>::load(pe + (int64_t)step * d + c, pp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = v[j] * s + pp[j];
+            o[j] = (p > 0.f) ? (hash_u32(seed, (uint64_t)(i + j)) >= thr ? t * sc : 0.f) : t;
+        }
+        V4<T>::store(out + i, o);
+    }
+}
+
+// probs = softmax(logits * inv_t): fp32 result (the user-visible [B,V] slab) + a copy in the
+// compute dtype into the next step's padded GEMM operand row.  One 256-thread block per row.
+template <typename T, int NE>
+__global__ __launch_bounds__(256) void vocab_softmax_kernel(const T* __restrict__ logits, int64_t ldl,
+                                                            float* __restrict__ probs, int64_t ldp,
+                                                            T* __restrict__ copy, int64_t ldc, int n, float inv_t) {
+    __shared__ float sm[4];
+    const int t = threadIdx.x, row = blockIdx.x;
+    float v[NE];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = t + i * 256;
+        v[i] = c < n ? to_f(logits[(int64_t)row * ldl + c]) * inv_t : -INFINITY;
+        mx = fmaxf(mx, v[i]);
+    }
+    mx = wave_max(mx);
+    if ((t & 63) == 0) sm[t >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        v[i] = (t + i * 256) < n ? expf(v[i] - mx) : 0.f;
+        sum += v[i];
+    }
+    sum = wave_sum(sum);
+    if ((t & 63) == 0) sm[t >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / ((sm[0] + sm[1]) + (sm[2] + sm[3]));
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = t + i * 256;
+        if (c < n) {
+            const float p = v[i] * inv;
+            probs[(int64_t)row * ldp + c] = p;
+            if (copy) copy[(int64_t)row * ldc + c] = from_f<T>(p);
+        }
+    }
+}
+
+struct Ctx {
+    const mssr_decode_plan* p;
+    hipStream_t s;
+    int dt;
+    size_t es;      // element size of the compute dtype
+};
+
+static inline char* at(void* base, int64_t elems, size_t es) { return (char*)base + elems * (int64_t)es; }
+
+// C[m, n] = A[m,k] . W[n,k]^T (+ epilogue) -- every decode GEMM has this NT, k-contiguous form
+static int gemm_nt(const Ctx& c, const void* a, int64_t lda, const void* w, int64_t ldw, void* out, int64_t ldc,
+                   int64_t m, int64_t n, int64_t k, const float* bias, int relu, const void* residual, int64_t ldr,
+                   const void* gate, int64_t ldg, float alpha, float beta, int out_dt, float drop_p, uint64_t seed) {
+    mssr_gemm_desc d;
+    d.a = a; d.b = w; d.c = out; d.bias = bias; d.residual = residual; d.gate = gate;
+    d.m = m; d.n = n; d.k = k;
+    d.a_rs = lda; d.a_cs = 1; d.b_rs = 1; d.b_cs = ldw;
+    d.ldc = ldc; d.ldr = ldr; d.ldg = ldg;
+    d.batch_outer = d.batch_inner = 1;
+    d.a_bo = d.a_bi = d.b_bo = d.b_bi = d.c_bo = d.c_bi = 0;
+    d.alpha = alpha; d.beta = beta; d.relu = relu;
+    d.in_dtype = c.dt; d.out_dtype = out_dt;
+    d.drop_p = drop_p; d.drop_seed = seed;
+    d.workspace = c.p->gemm_ws; d.workspace_bytes = c.p->gemm_ws_bytes; d.no_skinny = 0;
+    return mssr_gemm(&d, c.s);
+}
+
+static inline uint64_t site_seed(const mssr_decode_plan* p, int step, int layer, int site) {
+    return p->seed + (uint64_t)step * 0x100000001B3ull + (uint64_t)(layer + 1) * 0x9E3779B1ull + (uint64_t)site * 7919ull;
+}
+
+template <typename T>
+static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const void* k, const void* v, int64_t kv_bs,
+                            int64_t kv_ts, const uint8_t* mask, int64_t mask_bs, void* ctx, int64_t ctx_bs, int Lk,
+                            float p_drop, uint64_t seed) {
+    const mssr_decode_plan* p = c.p;
+    const int dh = p->d / p->heads;
+    const int bh = p->B * p->heads;
+    attn_step_fwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
+        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, p->B, p->heads, dh,
+        Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
+}
+
+template <typename T>
+static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const void* k, const void* v, int64_t kv_bs,
+                            int64_t kv_ts, const uint8_t* mask, int64_t mask_bs, const void* dctx, int64_t dctx_bs,
+                            void* dq, int64_t dq_bs, float* dk_acc, float* dv_acc, int64_t acc_bs, int64_t acc_ts,
+                            int fin_row, void* dk_out, void* dv_out, int64_t out_bs, int Lk, float p_drop,
+                            uint64_t seed) {
+    const mssr_decode_plan* p = c.p;
+    const int dh = p->d / p->heads;
+    const int bh = p->B * p->heads;
+    attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
+        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
+        dq_bs, dk_acc, dv_acc, acc_bs, acc_ts, fin_row, (T*)dk_out, (T*)dv_out, out_bs, p->B, p->heads, dh, Lk,
+        1.0f / sqrtf((float)dh), p_drop, seed);
+}
+
+#define DT_CALL(c, fn, ...)                                   \
+    do {                                                      \
+        if ((c).dt == MSSR_F32) fn<float>(__VA_ARGS__);       \
+        else fn<bf16>(__VA_ARGS__);                           \
+    } while (0)
+
+static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
+    MSSR_REQUIRE(p, "%s: null plan", who);
+    MSSR_REQUIRE(valid_dtype(p->dtype), "%s: bad dtype", who);
+    MSSR_REQUIRE(p->B > 0 && p->d > 0 && p->heads > 0 && p->d % p->heads == 0 && (p->d / p->heads) % 4 == 0 &&
+                     p->d % 8 == 0 && p->ff % 8 == 0 && p->n_layers > 0 && p->V > 0 && p->Vp >= p->V &&
+                     p->Vp % 32 == 0 && p->Ls > 0 && p->T > 0,
+                 "%s: bad dimensions", who);
+    MSSR_REQUIRE(step >= 0 && step < p->T, "%s: step %d outside [0, %d)", who, step, p->T);
+    MSSR_REQUIRE(p->T <= AT_MAXK && p->Ls <= AT_MAXK, "%s: more than %d keys", who, AT_MAXK);
+    MSSR_REQUIRE(p->V <= 16384, "%s: vocabulary above 16384", who);
+    MSSR_REQUIRE(p->d <= 4096, "%s: model dim above 4096", who);
+    MSSR_REQUIRE(p->layers && p->emb_t && p->pe && p->w_gen && p->b_gen && p->lnF_g && p->lnF_b && p->mem_kv &&
+                     p->src_mask && p->in_all && p->probs && p->X && p->qkv && p->actD && p->actF && p->stats &&
+                     p->nf && p->logits && p->tmp,
+                 "%s: null buffer in plan", who);
+    MSSR_REQUIRE(p->temperature > 0.f, "%s: temperature must be positive", who);
+    MSSR_REQUIRE(p->p_drop >= 0.f && p->p_drop < 1.f && p->p_attn >= 0.f && p->p_attn < 1.f, "%s: bad dropout", who);
+    return MSSR_OK;
+}
+
+}  // namespace mssr
+
+using namespace mssr;
+
+// Slab geometry (elements), shared by forward and backward.  Ts = save ? T : 1, slot = save ? step : 0.
+//   X     [n_layers+1][Ts][B,d]      residual stream entering layer l (l = n_layers: decoder output)
+//   qkv   [n_layers][T][B,3d]        packed self-attention projections = the K/V cache
+//   actD  [n_layers][8][Ts][B,d]     n1 | ctx1 | h1 | n2 | qc | ctx2 | h2 | n3
+//   actF  [n_layers][Ts][B,ff]       FFN inner activation (after ReLU and dropout)
+//   stats [3*n_layers+1][2][Ts][B]   LayerNorm mean, rstd (float)
+//   nf    [Ts][B,d]                  final LayerNorm output
+// Every quantity is contiguous over (step, batch), so the caller contracts weight gradients over
+// all steps with ONE product per parameter.
+enum { K_N1 = 0, K_CTX1, K_H1, K_N2, K_QC, K_CTX2, K_H2, K_N3, K_NKINDS };
+enum { G_DN1 = 0, G_DSO, G_DN2, G_DCQ, G_DCO, G_DN3, G_DF2, G_NKINDS };
+
+#define ENGINE_GEOMETRY(p, step)                                                    \
+    const int B = (p)->B, d = (p)->d, ff = (p)->ff, NL = (p)->n_layers;             \
+    const int Ts = (p)->save ? (p)->T : 1;                                          \
+    const int slot = (p)->save ? (step) : 0;                                        \
+    const int64_t Bd = (int64_t)B * d;                                              \
+    (void)ff; (void)NL; (void)Ts; (void)slot; (void)Bd;
+
+extern "C" int mssr_decode_step_fwd(const mssr_decode_plan* p, int step, void* stream) {
+    if (int e = check_plan(p, step, "decode_step_fwd")) return e;
+    Ctx c{p, (hipStream_t)stream, p->dtype, dsize(p->dtype)};
+    ENGINE_GEOMETRY(p, step);
+    const size_t es = c.es;
+    const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
+    int rc;
+    auto Xl = [&](int l) { return at(p->X, ((int64_t)l * Ts + slot) * Bd, es); };
+    auto ACT = [&](int l, int kind) { return at(p->actD, (((int64_t)l * K_NKINDS + kind) * Ts + slot) * Bd, es); };
+    auto ST = [&](int idx, int which) { return p->stats + (((int64_t)idx * 2 + which) * Ts + slot) * B; };
+
+    // embedding of the (soft) input: e = in[step] . E ; x0 = dropout(e*sqrt(d) + pe[step])
+    const void* in = at(p->in_all, (int64_t)step * B * p->Vp, es);
+    if ((rc = gemm_nt(c, in, p->Vp, p->emb_t, p->Vp, p->tmp, d, B, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
+                      0.f, c.dt, 0.f, 0)))
+        return rc;
+    {
+        const unsigned g = (unsigned)((Bd / 4 + 255) / 256);
+        if (c.dt == MSSR_F32)
+            embed_epilogue_kernel<float><<<g, 256, 0, c.s>>>((const float*)p->tmp, p->pe, (float*)Xl(0), B, d, step,
+                                                             sqrtf((float)d), pd, site_seed(p, step, -1, 0));
+        else
+            embed_epilogue_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)p->tmp, p->pe, (bf16*)Xl(0), B, d, step,
+                                                            sqrtf((float)d), pd, site_seed(p, step, -1, 0));
+    }
+    for (int l = 0; l < NL; ++l) {
+        const mssr_dec_layer& L = p->layers[l];
+        char* x = Xl(l);
+        char *n1 = ACT(l, K_N1), *ctx1 = ACT(l, K_CTX1), *h1 = ACT(l, K_H1), *n2 = ACT(l, K_N2), *qc = ACT(l, K_QC),
+             *ctx2 = ACT(l, K_CTX2), *h2 = ACT(l, K_H2), *n3 = ACT(l, K_N3);
+        char* inter = at(p->actF, ((int64_t)l * Ts + slot) * B * ff, es);
+        char* qkv_l = at(p->qkv, (int64_t)l * p->T * B * 3 * d, es);            // [T][B,3d]
+        char* qkv_s = qkv_l + (int64_t)step * B * 3 * d * es;
+        // --- self attention block
+        if ((rc = mssr_layernorm_fwd(x, L.ln1_g, L.ln1_b, n1, ST(l * 3 + 0, 0), ST(l * 3 + 0, 1), B, d, 1e-6f, c.dt,
+                                     c.s)))
+            return rc;
+        if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, 3 * d, B, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f, 0.f,
+                          c.dt, 0.f, 0)))
+            return rc;
+        DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_l + (int64_t)d * es, qkv_l + 2LL * d * es, 3 * d,
+                (int64_t)B * 3 * d, nullptr, 0, ctx1, d, step + 1, pa, site_seed(p, step, l, 1));
+        if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, B, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
+                          site_seed(p, step, l, 2))))
+            return rc;
+        // --- context attention block (keys / values of the memory bank were projected once)
+        if ((rc = mssr_layernorm_fwd(h1, L.ln2_g, L.ln2_b, n2, ST(l * 3 + 1, 0), ST(l * 3 + 1, 1), B, d, 1e-6f, c.dt,
+                                     c.s)))
+            return rc;
+        if ((rc = gemm_nt(c, n2, d, L.w_cq, d, qc, d, B, d, d, L.b_cq, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, 0.f,
+                          0)))
+            return rc;
+        const char* mkv = at((void*)p->mem_kv, (int64_t)l * 2 * d, es);         // [B, Ls, NL, 2d], layer l
+        DT_CALL(c, launch_attn_fwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
+                (int64_t)NL * 2 * d, p->src_mask, p->Ls, ctx2, d, p->Ls, pa, site_seed(p, step, l, 3));
+        if ((rc = gemm_nt(c, ctx2, d, L.w_co, d, h2, d, B, d, d, L.b_co, 0, h1, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
+                          site_seed(p, step, l, 4))))
+            return rc;
+        // --- feed forward block
+        if ((rc = mssr_layernorm_fwd(h2, L.lnf_g, L.lnf_b, n3, ST(l * 3 + 2, 0), ST(l * 3 + 2, 1), B, d, 1e-6f, c.dt,
+                                     c.s)))
+            return rc;
+        if ((rc = gemm_nt(c, n3, d, L.w_1, d, inter, ff, B, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, pd,
+                          site_seed(p, step, l, 5))))
+            return rc;
+        if ((rc = gemm_nt(c, inter, ff, L.w_2, ff, Xl(l + 1), d, B, d, ff, L.b_2, 0, h2, d, nullptr, 0, 1.f, 0.f, c.dt,
+                          pd, site_seed(p, step, l, 6))))
+            return rc;
+    }
+    // final LayerNorm, generator Linear, softmax(/T)
+    char* nf = at(p->nf, (int64_t)slot * Bd, es);
+    if ((rc = mssr_layernorm_fwd(Xl(NL), p->lnF_g, p->lnF_b, nf, ST(NL * 3, 0), ST(NL * 3, 1), B, d, 1e-6f, c.dt, c.s)))
+        return rc;
+    if ((rc = gemm_nt(c, nf, d, p->w_gen, d, p->logits, p->Vp, B, p->V, d, p->b_gen, 0, nullptr, 0, nullptr, 0, 1.f,
+                      0.f, c.dt, 0.f, 0)))
+        return rc;
+    float* probs = p->probs + (int64_t)step * B * p->V;
+    void* copy = at(p->in_all, (int64_t)(step + 1) * B * p->Vp, es);      // in_all has T+1 slots
+    const int ne = (p->V + 255) / 256;
+#define VS(T, NEc)                                                                                          \
+    vocab_softmax_kernel<T, NEc><<<B, 256, 0, c.s>>>((const T*)p->logits, p->Vp, probs, p->V, (T*)copy, p->Vp, \
+                                                     p->V, 1.0f / p->temperature)
+    if (c.dt == MSSR_F32) {
+        if (ne <= 8) VS(float, 8); else if (ne <= 16) VS(float, 16); else if (ne <= 40) VS(float, 40); else VS(float, 64);
+    } else {
+        if (ne <= 8) VS(bf16, 8); else if (ne <= 16) VS(bf16, 16); else if (ne <= 40) VS(bf16, 40); else VS(bf16, 64);
+    }
+#undef VS
+    MSSR_LAUNCH_OK("decode_step_fwd");
+}
+
+extern "C" int mssr_decode_step_bwd(const mssr_decode_plan* p, int step, void* stream) {
+    if (int e = check_plan(p, step, "decode_step_bwd")) return e;
+    MSSR_REQUIRE(p->save, "decode_step_bwd: the forward did not save activations (save = 0)");
+    MSSR_REQUIRE(p->emb && p->wt_gen && p->dprobs && p->dlogits && p->dX && p->dqkv && p->dactD && p->dactF &&
+                     p->dkv_acc && p->dmem_acc && p->d_e && p->dnf,
+                 "decode_step_bwd: null gradient buffer in plan");
+    Ctx c{p, (hipStream_t)stream, p->dtype, dsize(p->dtype)};
+    ENGINE_GEOMETRY(p, step);
+    const size_t es = c.es;
+    const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
+    const float keep = pd > 0.f ? 1.0f / (1.0f - pd) : 1.0f;
+    int rc;
+    auto Xl = [&](int l) { return at(p->X, ((int64_t)l * Ts + slot) * Bd, es); };
+    auto ACT = [&](int l, int kind) { return at(p->actD, (((int64_t)l * K_NKINDS + kind) * Ts + slot) * Bd, es); };
+    auto ST = [&](int idx, int which) { return p->stats + (((int64_t)idx * 2 + which) * Ts + slot) * B; };
+    // gradient slabs: dactD [n_layers][7][T][B,d] = dn1 | d_so | dn2 | d_cq | d_co | dn3 | d_f2 (gradients of the
+    // outputs of LN1, self out-proj, LN2, ctx query proj, ctx out-proj, LN3, W2); dactF [n_layers][T][B,ff] = d_f1
+    auto DACT = [&](int l, int kind) { return at(p->dactD, (((int64_t)l * G_NKINDS + kind) * p->T + step) * Bd, es); };
+    auto drop_replay = [&](const void* x, void* y, int64_t n, uint64_t seed, float extra) {
+        const unsigned g = (unsigned)((n / 4 + 255) / 256);
+        if (c.dt == MSSR_F32) drop_replay_kernel<float><<<g, 256, 0, c.s>>>((const float*)x, (float*)y, n, pd, seed, extra);
+        else drop_replay_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)x, (bf16*)y, n, pd, seed, extra);
+    };
+    auto ln_bwd = [&](const void* dy, const void* x, const float* g, int idx, const void* dres, void* dx) {
+        if (c.dt == MSSR_F32)
+            ln_bwd_dx_kernel<float><<<(B + 3) / 4, 256, 0, c.s>>>((const float*)dy, (const float*)x, g, ST(idx, 0),
+                                                                 ST(idx, 1), (const float*)dres, (float*)dx, B, d);
+        else
+            ln_bwd_dx_kernel<bf16><<<(B + 3) / 4, 256, 0, c.s>>>((const bf16*)dy, (const bf16*)x, g, ST(idx, 0),
+                                                                ST(idx, 1), (const bf16*)dres, (bf16*)dx, B, d);
+    };
+
+    // softmax backward: dlogits[step] (compute dtype, padded columns stay zero)
+    char* dlg = at(p->dlogits, (int64_t)step * B * p->Vp, es);
+    const float* probs = p->probs + (int64_t)step * B * p->V;
+    const float* dpr = p->dprobs + (int64_t)step * B * p->V;
+    if ((rc = mssr_softmax_bwd(probs, dpr, dlg, B, p->V, p->V, p->V, p->Vp, 1.0f / p->temperature, 0, MSSR_F32,
+                               MSSR_F32, c.dt, c.s)))
+        return rc;
+    // generator Linear: dnf = dlogits . W_gen   (W as [N=d, K=Vp] = wt_gen)
+    char* dnf = at(p->dnf, (int64_t)step * Bd, es);
+    if ((rc = gemm_nt(c, dlg, p->Vp, p->wt_gen, p->Vp, dnf, d, B, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
+                      0.f, c.dt, 0.f, 0)))
+        return rc;
+    char* dx = (char*)p->dX;                   // running gradient of the residual stream [B,d]
+    ln_bwd(dnf, Xl(NL), p->lnF_g, NL * 3, nullptr, dx);
+    for (int l = NL - 1; l >= 0; --l) {
+        const mssr_dec_layer& L = p->layers[l];
+        char *h1 = ACT(l, K_H1), *qc = ACT(l, K_QC), *h2 = ACT(l, K_H2);
+        char* inter = at(p->actF, ((int64_t)l * Ts + slot) * B * ff, es);
+        char *dn1 = DACT(l, G_DN1), *d_so = DACT(l, G_DSO), *dn2 = DACT(l, G_DN2), *d_cq = DACT(l, G_DCQ),
+             *d_co = DACT(l, G_DCO), *dn3 = DACT(l, G_DN3), *d_f2 = DACT(l, G_DF2);
+        char* d_f1 = at(p->dactF, ((int64_t)l * p->T + step) * B * ff, es);
+        char* qkv_l = at(p->qkv, (int64_t)l * p->T * B * 3 * d, es);
+        char* qkv_s = qkv_l + (int64_t)step * B * 3 * d * es;
+        char* dqkv_s = at(p->dqkv, ((int64_t)l * p->T + step) * B * 3 * d, es);
+        // --- feed forward block: y = h2 + drop(W2 inter + b2), inter = drop(relu(W1 n3 + b1))
+        if (pd > 0.f) drop_replay(dx, d_f2, Bd, site_seed(p, step, l, 6), 1.f);
+        else (void)hipMemcpyAsync(d_f2, dx, Bd * es, hipMemcpyDeviceToDevice, c.s);
+        // d_f1 = (d_f2 . W2) * (inter > 0) / (1-p)      [W as [N=ff, K=d] = wt_2]
+        if ((rc = gemm_nt(c, d_f2, d, L.wt_2, d, d_f1, ff, B, ff, d, nullptr, 0, nullptr, 0, inter, ff, keep, 0.f, c.dt,
+                          0.f, 0)))
+            return rc;
+        if ((rc = gemm_nt(c, d_f1, ff, L.wt_1, ff, dn3, d, B, d, ff, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                          0.f, 0)))
+            return rc;
+        ln_bwd(dn3, h2, L.lnf_g, l * 3 + 2, dx, dx);                     // dx <- grad wrt h2
+        // --- context attention block: h2 = h1 + drop(Wco ctx2 + bco)
+        if (pd > 0.f) drop_replay(dx, d_co, Bd, site_seed(p, step, l, 4), 1.f);
+        else (void)hipMemcpyAsync(d_co, dx, Bd * es, hipMemcpyDeviceToDevice, c.s);
+        if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, p->tmp, d, B, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                          0.f, 0)))
+            return rc;                                                    // tmp = dctx2
+        {
+            const char* mkv = at((void*)p->mem_kv, (int64_t)l * 2 * d, es);
+            float* macc = p->dmem_acc + (int64_t)l * 2 * d;                // [B, Ls, NL, 2d] float, layer l
+            DT_CALL(c, launch_attn_bwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
+                    (int64_t)NL * 2 * d, p->src_mask, p->Ls, p->tmp, d, d_cq, d, macc, macc + d,
+                    (int64_t)p->Ls * NL * 2 * d, (int64_t)NL * 2 * d, -1, nullptr, nullptr, 0, p->Ls, pa,
+                    site_seed(p, step, l, 3));
+        }
+        if ((rc = gemm_nt(c, d_cq, d, L.wt_cq, d, dn2, d, B, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                          0.f, 0)))
+            return rc;
+        ln_bwd(dn2, h1, L.ln2_g, l * 3 + 1, dx, dx);                     // dx <- grad wrt h1
+        // --- self attention block: h1 = x + drop(Wso ctx1 + bso)
+        if (pd > 0.f) drop_replay(dx, d_so, Bd, site_seed(p, step, l, 2), 1.f);
+        else (void)hipMemcpyAsync(d_so, dx, Bd * es, hipMemcpyDeviceToDevice, c.s);
+        if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, p->tmp, d, B, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                          0.f, 0)))
+            return rc;                                                    // tmp = dctx1
+        {
+            float* kacc = p->dkv_acc + (int64_t)l * p->T * B * 2 * d;      // [T][B, 2d] float
+            DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_l + (int64_t)d * es, qkv_l + 2LL * d * es, 3 * d,
+                    (int64_t)B * 3 * d, nullptr, 0, p->tmp, d, dqkv_s, 3 * d, kacc, kacc + d, 2 * d, (int64_t)B * 2 * d,
+                    step, dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa,
+                    site_seed(p, step, l, 1));
+        }
+        if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, B, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
+                          0.f, c.dt, 0.f, 0)))
+            return rc;
+        ln_bwd(dn1, Xl(l), L.ln1_g, l * 3 + 0, dx, dx);                  // dx <- grad wrt layer input
+    }
+    // embedding: x0 = drop(e*sqrt(d) + pe)  ->  d_e ; feedback into the previous step's probabilities
+    char* de = at(p->d_e, (int64_t)step * Bd, es);
+    if (pd > 0.f) drop_replay(dx, de, Bd, site_seed(p, step, -1, 0), sqrtf((float)d));
+    else {
+        if ((rc = mssr_axpby(dx, nullptr, de, Bd, sqrtf((float)d), 0.f, c.dt, c.s))) return rc;
+    }
+    if (step > 0) {
+        float* dprev = p->dprobs + (int64_t)(step - 1) * B * p->V;
+        // dprobs[step-1] += d_e . E^T      (W as [N=V, K=d] = E itself)
+        if ((rc = gemm_nt(c, de, d, p->emb, d, dprev, p->V, B, p->V, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 1.f,
+                          MSSR_F32, 0.f, 0)))
+            return rc;
+    }
+    MSSR_LAUNCH_OK("decode_step_bwd");
+}
+
+// All T steps forward (0 .. T-1) / backward (T-1 .. 0) in one call: the whole decode is one host
+// round trip, every kernel enqueued back to back on `stream`.
+extern "C" int mssr_decode_fwd(const mssr_decode_plan* p, void* stream) {
+    MSSR_REQUIRE(p, "decode_fwd: null plan");
+    for (int s = 0; s < p->T; ++s)
+        if (int rc = mssr_decode_step_fwd(p, s, stream)) return rc;
+    return MSSR_OK;
+}
+
+extern "C" int mssr_decode_bwd(const mssr_decode_plan* p, void* stream) {
+    MSSR_REQUIRE(p, "decode_bwd: null plan");
+    for (int s = p->T - 1; s >= 0; --s)
+        if (int rc = mssr_decode_step_bwd(p, s, stream)) return rc;
+    return MSSR_OK;
+}

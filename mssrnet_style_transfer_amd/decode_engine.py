@@ -1,0 +1,291 @@
+"""Host side of the step-wise soft-decode engine (csrc/decode.hip, include/mssr_hip.h).
+
+``soft_decode(model, cfg, memory_bank, src_lengths, steps)`` is the differentiable decoding of
+the reference -- TrainTranslator.decode_batch_ori (onmt/train_and_translate.py:202-231):
+one-hot ``<s>`` -> TransformerDecoder.forward(step=s) (onmt/decoders/transformer.py:289-337)
+-> generator Linear -> softmax(/temperature) -> fed back as the next soft input -- as ONE
+autograd node.  The forward is a single C call that enqueues every kernel of all steps; the
+backward is a single C call for the reverse sweep plus one product per parameter that
+contracts the per-step gradient slabs over all (step, sentence) rows at once.
+
+The K/V "cache" is the step-major slab of packed projections, so nothing is concatenated as the
+sequence grows (the reference re-copies the cache every step, multi_headed_attn.py:139-148).
+Packed / transposed copies of the decoder weights in the compute dtype are rebuilt only when
+a parameter's version changes (i.e. after an optimizer step).
+"""
+import ctypes
+import math
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from . import ops
+
+N_HEAD_PARAMS = 5
+N_LAYER_PARAMS = 26
+# indices into a layer's parameter list (see _layer_params)
+(_WQ, _BQ, _WK, _BK, _WV, _BV, _WSO, _BSO, _WCK, _BCK, _WCV, _BCV, _WCQ, _BCQ, _WCO, _BCO, _W1, _B1, _W2, _B2,
+ _LN1G, _LN1B, _LN2G, _LN2B, _LNFG, _LNFB) = range(N_LAYER_PARAMS)
+# slab kinds (csrc/decode.hip)
+K_N1, K_CTX1, K_H1, K_N2, K_QC, K_CTX2, K_H2, K_N3 = range(8)
+G_DN1, G_DSO, G_DN2, G_DCQ, G_DCO, G_DN3, G_DF2 = range(7)
+
+
+def _layer_params(layer):
+    sa, ca, ff = layer.self_attn, layer.context_attn, layer.feed_forward
+    return [sa.linear_query.weight, sa.linear_query.bias, sa.linear_keys.weight, sa.linear_keys.bias,
+            sa.linear_values.weight, sa.linear_values.bias, sa.final_linear.weight, sa.final_linear.bias,
+            ca.linear_keys.weight, ca.linear_keys.bias, ca.linear_values.weight, ca.linear_values.bias,
+            ca.linear_query.weight, ca.linear_query.bias, ca.final_linear.weight, ca.final_linear.bias,
+            ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias,
+            layer.layer_norm_1.weight, layer.layer_norm_1.bias, layer.layer_norm_2.weight, layer.layer_norm_2.bias,
+            ff.layer_norm.weight, ff.layer_norm.bias]
+
+
+def decoder_params(model):
+    """[E, lnF_g, lnF_b, W_gen, b_gen] + 26 parameters per decoder layer, in a fixed order."""
+    dec, gen = model.decoder, model.generator[0]
+    out = [dec.embeddings.word_lut.weight, dec.layer_norm.weight, dec.layer_norm.bias, gen.weight, gen.bias]
+    for layer in dec.transformer_layers:
+        out += _layer_params(layer)
+    return out
+
+
+class _Pack:
+    """Decoder + generator weights as the engine wants them (compute dtype, packed, transposed)."""
+
+    def __init__(self, params, n_layers, cd):
+        E, lnFg, lnFb, Wg, bg = params[:N_HEAD_PARAMS]
+        lp = [params[N_HEAD_PARAMS + i * N_LAYER_PARAMS: N_HEAD_PARAMS + (i + 1) * N_LAYER_PARAMS]
+              for i in range(n_layers)]
+        NL = n_layers
+        V, d = E.shape
+        ff = lp[0][_W1].shape[0]
+        Vp = (V + 31) // 32 * 32
+        self.NL, self.V, self.Vp, self.d, self.ff, self.cd = NL, V, Vp, d, ff, cd
+        with torch.no_grad():
+            def rows(idx):          # rows of the given per-layer parameters, layer-major
+                return torch.cat([lp[l][i].detach() for l in range(NL) for i in idx], 0)
+
+            def w(idx, n_out, n_in):
+                t = rows(idx).to(cd).view(NL, n_out, n_in)
+                return t, t.transpose(1, 2).contiguous()
+
+            def f(idx, n):
+                return rows(idx).float().view(NL, n).contiguous()
+
+            self.w_qkv, self.wt_qkv = w([_WQ, _WK, _WV], 3 * d, d)
+            self.w_so, self.wt_so = w([_WSO], d, d)
+            self.w_cq, self.wt_cq = w([_WCQ], d, d)
+            self.w_co, self.wt_co = w([_WCO], d, d)
+            self.w_1, self.wt_1 = w([_W1], ff, d)
+            self.w_2, self.wt_2 = w([_W2], d, ff)
+            self.w_ckv = rows([_WCK, _WCV]).to(cd).contiguous()            # [NL*2d, d]
+            self.b_ckv = rows([_BCK, _BCV]).float().contiguous()           # [NL*2d]
+            self.b_qkv, self.b_so, self.b_cq, self.b_co = f([_BQ, _BK, _BV], 3 * d), f([_BSO], d), f([_BCQ], d), \
+                f([_BCO], d)
+            self.b_1, self.b_2 = f([_B1], ff), f([_B2], d)
+            self.ln1_g, self.ln1_b, self.ln2_g, self.ln2_b = f([_LN1G], d), f([_LN1B], d), f([_LN2G], d), f([_LN2B], d)
+            self.lnf_g, self.lnf_b = f([_LNFG], d), f([_LNFB], d)
+            self.emb = E.detach().to(cd).contiguous()                      # [V, d]
+            self.emb_t = torch.zeros(d, Vp, dtype=cd, device=E.device)
+            self.emb_t[:, :V] = self.emb.t()
+            self.w_gen = Wg.detach().to(cd).contiguous()                   # [V, d]
+            self.wt_gen = torch.zeros(d, Vp, dtype=cd, device=E.device)
+            self.wt_gen[:, :V] = self.w_gen.t()
+            self.b_gen = bg.detach().float().contiguous()
+            self.lnF_g, self.lnF_b = lnFg.detach().float().contiguous(), lnFb.detach().float().contiguous()
+        arr = (L.DecLayer * NL)()
+        for l in range(NL):
+            for name in ("w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2",
+                         "wt_2", "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                         "lnf_g", "lnf_b"):
+                setattr(arr[l], name, getattr(self, name)[l].data_ptr())
+        self.layers = arr
+
+
+_pack_cache = {}
+
+
+def get_pack(model, params):
+    """The packed weights of ``model``'s decoder, rebuilt when any parameter changed in place."""
+    cd = ops.compute_dtype()
+    key = id(model)
+    ver = (cd, tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:2]))
+    hit = _pack_cache.get(key)
+    if hit is not None and hit[0] == ver:
+        return hit[1]
+    pack = _Pack(params, len(model.decoder.transformer_layers), cd)
+    _pack_cache[key] = (ver, pack)
+    return pack
+
+
+def clear_pack_cache():
+    _pack_cache.clear()
+
+
+class _Spec:
+    """Everything about one decode call that is not a tensor autograd tracks."""
+    __slots__ = ("pack", "B", "Ls", "T", "heads", "training", "p_drop", "p_attn", "temperature", "seed", "src_mask",
+                 "bos", "pe", "save")
+
+
+def _bgemm_t(dy, x):
+    """sum over rows of dy[.., R, n]^T x[.., R, k] -> float [.., n, k] (a weight gradient)."""
+    return ops.gemm(dy.transpose(-1, -2), x, False, torch.float32)
+
+
+def _bsum(dy):
+    """column sums of dy [NL, R, n] (bias gradients) as a product with a row of ones -> float [NL, n]."""
+    ones = torch.ones(1, 1, dy.shape[-2], dtype=dy.dtype, device=dy.device).expand(dy.shape[0], 1, dy.shape[-2])
+    return ops.gemm(ones, dy, False, torch.float32).squeeze(1)
+
+
+class _SoftDecode(Function):
+    @staticmethod
+    def forward(ctx, spec, mem, *params):
+        pk = spec.pack
+        lib = L.load()
+        cd, dev = pk.cd, mem.device
+        B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
+        L.require_cuda(mem)
+        memc = ops.cast(mem).detach().contiguous().view(B * Ls, d)
+        # context keys|values of the memory bank for every layer in one product: [B*Ls, NL*2d]
+        mem_kv = ops.gemm(memc, pk.w_ckv, True, cd, bias=pk.b_ckv)
+        Ts = T if spec.save else 1
+        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        bufs = dict(
+            mem=memc, mem_kv=mem_kv,
+            in_all=torch.zeros(T + 1, B, Vp, dtype=cd, device=dev),
+            probs=e(T, B, V, dtype=torch.float32),
+            X=e(NL + 1, Ts * B, d), qkv=e(NL, T * B, 3 * d), actD=e(NL, 8, Ts * B, d), actF=e(NL, Ts * B, ff),
+            stats=e(3 * NL + 1, 2, Ts * B, dtype=torch.float32), nf=e(Ts * B, d), logits=e(B, Vp), tmp=e(B, d),
+            ws=ops._workspace(dev))
+        bufs["in_all"][0, :, spec.bos] = 1
+        plan = L.DecodePlan()
+        plan.dtype = L.F32 if cd == torch.float32 else L.BF16
+        plan.B, plan.d, plan.heads, plan.ff, plan.n_layers = B, d, spec.heads, ff, NL
+        plan.V, plan.Vp, plan.Ls, plan.T = V, Vp, Ls, T
+        plan.save, plan.training = int(spec.save), int(spec.training)
+        plan.p_drop, plan.p_attn, plan.temperature, plan.seed = spec.p_drop, spec.p_attn, spec.temperature, spec.seed
+        plan.layers = pk.layers
+        for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b"):
+            setattr(plan, name, getattr(pk, name).data_ptr())
+        plan.pe = spec.pe.data_ptr()
+        plan.src_mask = spec.src_mask.data_ptr()
+        for name in ("mem_kv", "in_all", "probs", "X", "qkv", "actD", "actF", "stats", "nf", "logits", "tmp"):
+            setattr(plan, name, bufs[name].data_ptr())
+        plan.gemm_ws, plan.gemm_ws_bytes = bufs["ws"].data_ptr(), bufs["ws"].numel() * 4
+        L.check(lib.mssr_decode_fwd(ctypes.byref(plan), L.stream()), "decode_fwd")
+        probs = bufs.pop("probs")
+        if spec.save:
+            ctx.spec, ctx.plan, ctx.bufs = spec, plan, bufs
+            ctx.mem_meta = (mem.shape, mem.dtype)
+            ctx.save_for_backward(probs)        # read by the softmax backward of every step
+        return probs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dprobs):
+        spec, plan, bufs = ctx.spec, ctx.plan, ctx.bufs
+        if bufs is None:
+            raise RuntimeError("soft decode: backward called twice (activations were released)")
+        probs, = ctx.saved_tensors
+        assert probs.data_ptr() == plan.probs
+        pk = spec.pack
+        lib = L.load()
+        cd, dev = pk.cd, dprobs.device
+        B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
+        R = T * B
+        z = lambda *shape, dtype=cd: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
+        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        g = dict(dprobs=dprobs.to(torch.float32).clone(memory_format=torch.contiguous_format),
+                 dlogits=z(R, Vp), dX=e(B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
+                 dkv_acc=z(NL, R, 2 * d, dtype=torch.float32), dmem_acc=z(B * Ls, NL * 2 * d, dtype=torch.float32),
+                 d_e=e(R, d), dnf=e(R, d))
+        for name, t in g.items():
+            setattr(plan, name, t.data_ptr())
+        L.check(lib.mssr_decode_bwd(ctypes.byref(plan), L.stream()), "decode_bwd")
+
+        actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
+        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, K_N1]), _bsum(dqkv)
+        gW_so, gb_so = _bgemm_t(dactD[:, G_DSO], actD[:, K_CTX1]), _bsum(dactD[:, G_DSO])
+        gW_cq, gb_cq = _bgemm_t(dactD[:, G_DCQ], actD[:, K_N2]), _bsum(dactD[:, G_DCQ])
+        gW_co, gb_co = _bgemm_t(dactD[:, G_DCO], actD[:, K_CTX2]), _bsum(dactD[:, G_DCO])
+        gW_1, gb_1 = _bgemm_t(dactF, actD[:, K_N3]), _bsum(dactF)
+        gW_2, gb_2 = _bgemm_t(dactD[:, G_DF2], actF), _bsum(dactD[:, G_DF2])
+        # context key/value projections of the memory bank: one product over all layers
+        dmem_kv = g["dmem_acc"].to(cd)
+        gW_ckv = _bgemm_t(dmem_kv, bufs["mem"]).view(NL, 2 * d, d)
+        gb_ckv = ops.gemm(torch.ones(1, B * Ls, dtype=cd, device=dev), dmem_kv, False, torch.float32).view(NL, 2 * d)
+        g_mem = None
+        if ctx.needs_input_grad[1]:
+            shape, dtype = ctx.mem_meta
+            g_mem = ops.gemm(dmem_kv, pk.w_ckv, False, cd).view(shape).to(dtype)
+        # LayerNorm gains / biases: sum over all (step, sentence) rows
+        stats = bufs["stats"]
+        parts = lib.mssr_layernorm_partial_rows(R)
+        ws = e(2 * parts * d, dtype=torch.float32)
+        scratch = e(R, d)
+        ln_g = e(3 * NL + 1, 2, d, dtype=torch.float32)
+
+        def ln_grad(idx, dy, x, gamma):
+            L.check(lib.mssr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[idx, 0].data_ptr(),
+                                           stats[idx, 1].data_ptr(), scratch.data_ptr(), ln_g[idx, 0].data_ptr(),
+                                           ln_g[idx, 1].data_ptr(), ws.data_ptr(), R, d, plan.dtype, L.stream()),
+                    "layernorm_bwd")
+
+        for l in range(NL):
+            ln_grad(3 * l + 0, dactD[l, G_DN1], X[l], pk.ln1_g[l])
+            ln_grad(3 * l + 1, dactD[l, G_DN2], actD[l, K_H1], pk.ln2_g[l])
+            ln_grad(3 * l + 2, dactD[l, G_DN3], actD[l, K_H2], pk.lnf_g[l])
+        ln_grad(3 * NL, g["dnf"], X[NL], pk.lnF_g)
+        # generator and (soft) embedding table
+        dlg = g["dlogits"][:, :V]
+        gW_gen = _bgemm_t(dlg, bufs["nf"])
+        gb_gen = ops.gemm(torch.ones(1, R, dtype=cd, device=dev), dlg, False, torch.float32).view(V)
+        gE = _bgemm_t(bufs["in_all"][:T].view(R, Vp)[:, :V], g["d_e"])
+
+        out = [None, g_mem, gE, ln_g[3 * NL, 0], ln_g[3 * NL, 1], gW_gen, gb_gen]
+        for l in range(NL):
+            out += [gW_qkv[l, :d], gb_qkv[l, :d], gW_qkv[l, d:2 * d], gb_qkv[l, d:2 * d], gW_qkv[l, 2 * d:],
+                    gb_qkv[l, 2 * d:], gW_so[l], gb_so[l],
+                    gW_ckv[l, :d], gb_ckv[l, :d], gW_ckv[l, d:], gb_ckv[l, d:], gW_cq[l], gb_cq[l], gW_co[l], gb_co[l],
+                    gW_1[l], gb_1[l], gW_2[l], gb_2[l],
+                    ln_g[3 * l, 0], ln_g[3 * l, 1], ln_g[3 * l + 1, 0], ln_g[3 * l + 1, 1], ln_g[3 * l + 2, 0],
+                    ln_g[3 * l + 2, 1]]
+        ctx.bufs = ctx.plan = None
+        return tuple(out)
+
+
+def soft_decode(model, cfg, memory_bank, src_lengths, steps):
+    """vocab_probs [steps, B, V] (float) of the step-wise soft decode of ``model`` over
+    ``memory_bank`` [Ls, B, d] (the bonded encoder states)."""
+    dec = model.decoder
+    params = decoder_params(model)
+    pack = get_pack(model, params)
+    Ls, B, d = memory_bank.shape
+    layer0 = dec.transformer_layers[0]
+    spec = _Spec()
+    spec.pack, spec.B, spec.Ls, spec.T = pack, B, Ls, int(steps)
+    spec.heads = layer0.self_attn.head_count
+    spec.training = bool(dec.training)
+    spec.p_drop, spec.p_attn = float(layer0.drop.p), float(layer0.self_attn.dropout.p)
+    emb_p = float(dec.embeddings.make_embedding[1].dropout.p)
+    if spec.training and abs(emb_p - spec.p_drop) > 1e-12:
+        raise NotImplementedError("decode engine: embedding dropout (%g) must equal the layer dropout (%g)"
+                                  % (emb_p, spec.p_drop))
+    spec.temperature = float(cfg.dec_temperature)
+    spec.seed = ops.next_seed()
+    pos = torch.arange(Ls, device=memory_bank.device).unsqueeze(0)
+    spec.src_mask = (pos >= src_lengths.unsqueeze(1)).to(torch.uint8).contiguous()        # [B, Ls], 1 = pad
+    spec.bos = cfg.bos_idx
+    spec.pe = dec.embeddings.make_embedding[1].table()
+    if spec.T > spec.pe.shape[0]:
+        raise ValueError("decode engine: %d steps exceed the positional table" % spec.T)
+    needs = torch.is_grad_enabled() and (memory_bank.requires_grad or any(p.requires_grad for p in params))
+    spec.save = bool(needs)
+    mem = memory_bank.transpose(0, 1).contiguous()          # [B, Ls, d]
+    return _SoftDecode.apply(spec, mem, *params)

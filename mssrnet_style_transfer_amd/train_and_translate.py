@@ -8,6 +8,7 @@ module-level cache protocol of TransformerDecoder.
 import torch
 
 from . import ops
+from .decode_engine import soft_decode
 
 
 def convert_to_onehot(labels, vocab_size, device, dtype=torch.float32):
@@ -45,7 +46,20 @@ def fetch_dec_output_length(vocab_probs, cfg):
 
 
 def decode_batch_ori(model, cfg, src, enc_states, memory_bank, src_lengths, max_dec_steps=None):
-    """Returns (vocab_probs [steps,B,V] fp32, seq_lens list, pred_ids [steps,B])."""
+    """Returns (vocab_probs [steps,B,V] fp32, seq_lens list, pred_ids [steps,B]).  The whole
+    step loop runs inside the decode engine (decode_engine.soft_decode: one autograd node, one C
+    call per direction); ``decode_batch_modular`` below is the same loop over the module-level
+    cache protocol, kept as the drop-in surface and as the engine's cross-check."""
+    if max_dec_steps is None:
+        max_dec_steps = cfg.max_dec_steps
+    model.decoder.init_state(src, memory_bank, enc_states)
+    vocab_probs = soft_decode(model, cfg, memory_bank, src_lengths, max_dec_steps)
+    seq_lens, pred_ids = fetch_dec_output_length(vocab_probs, cfg)
+    return vocab_probs, seq_lens, pred_ids
+
+
+def decode_batch_modular(model, cfg, src, enc_states, memory_bank, src_lengths, max_dec_steps=None):
+    """decode_batch_ori through TransformerDecoder.forward(step=s) and the layer_cache dicts."""
     if max_dec_steps is None:
         max_dec_steps = cfg.max_dec_steps
     B = src_lengths.size(0)
