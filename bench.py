@@ -43,7 +43,7 @@ def roofline(records, dtype):
     its launches / the sum of their HIP-event durations."""
     agg = {}
     for r in records:
-        a = agg.setdefault(r["kernel"], dict(ms=0.0, bytes=0, flops=0, launches=0))
+        a = agg.setdefault(r["kernel"], dict(ms=0.0, bytes=0, flops=0, launches=0, key=r["in_dtype"]))
         a["ms"] += r["ms"]
         a["bytes"] += r["bytes"]
         a["flops"] += r["flops"]
@@ -52,7 +52,7 @@ def roofline(records, dtype):
         return None
     name, a = max(agg.items(), key=lambda kv: kv[1]["ms"])
     sec = a["ms"] * 1e-3
-    key = "bf16" if "bf16" in name.split(",")[0] else "f32"
+    key = a["key"]
     ridge = MFMA_PEAK_TFLOPS[key] * 1e12 / (HBM_PEAK_GBS * 1e9)
     if a["flops"] / max(a["bytes"], 1) < ridge:
         ach, peak, unit, bound = a["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"

@@ -86,20 +86,44 @@ typedef struct {
      * hash as mssr_dropout_fwd, so a backward pass can regenerate the mask from the seed. */
     float drop_p;
     uint64_t drop_seed;
-    /* optional fp32 scratch for the split-K slabs of the skinny-M kernel (m <= 128, k > 1024):
-     * ceil(k/1024) * m * n floats.  NULL: such problems use the general kernel. */
+    /* optional fp32 scratch for the split-K slabs of the skinny-M kernel (m <= 128, k > 2048):
+     * ceil(k/2048) * m * n floats.  NULL: such problems use the general kernel. */
     void* workspace;
     int64_t workspace_bytes;
     int no_skinny;   /* 1 = always use the general tiled kernel */
+    /* LayerNorm folded into the product (`LN -> Linear`, onmt/decoders/transformer.py:150-157,
+     * onmt/modules/position_ffn.py:35), skinny kernel only (bf16, m <= 128, k <= 2048): when ln_colsum
+     * is non-NULL, A holds the RAW rows x, B holds gamma-scaled weights W'[n,k] = gamma[k] W[n,k],
+     * ln_colsum[n] = sum_k W'[n,k], bias[n] = sum_k beta[k] W[n,k] + b[n], and the result is
+     *   rstd_m (acc - mean_m ln_colsum[n]) + bias[n]  ( = LN(x) W^T + b ), then the usual epilogue.
+     * The row statistics (biased variance, ln_eps inside the sqrt) go to ln_mean / ln_rstd [m] if non-NULL. */
+    const float* ln_colsum;
+    float* ln_mean;
+    float* ln_rstd;
+    float ln_eps;
 } mssr_gemm_desc;
 int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
 /* Block tile edge (64 or 32) mssr_gemm picks for an m x n x batch problem; lets a profiler name the
  * kernel instance (gemm_kernel<.., 64, 64> / <.., 32, 32>) a launch used.  No reference counterpart. */
 int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);
 /* 1 when mssr_gemm would route `desc` to the skinny-M kernel (m <= 128, bf16, both operands
- * k-contiguous and 16-byte aligned, k a multiple of 32): C = A[m,k] . W[n,k]^T with the block's four
- * waves splitting K and loading straight into MFMA fragments.  No reference counterpart. */
+ * k-contiguous and 16-byte aligned, k a multiple of 32): C = A[m,k] . W[n,k]^T, one block per 16x16
+ * output tile, its four waves splitting K and loading straight into MFMA fragments.  No reference
+ * counterpart. */
 int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
+
+/* Launch timing for the benchmark's roofline (no reference counterpart): between mssr_prof_start
+ * and mssr_prof_stop every mssr_gemm launch -- direct or from inside the decode engine -- is
+ * bracketed by HIP events on the stream it is enqueued on.  kernel: 0 = gemm_kernel (tile = 32/64),
+ * 1 = gemm_skinny_kernel (tile = number of split-K slabs).  Not thread-safe; host-side only. */
+typedef struct {
+    int kernel, in_dtype, out_dtype, tile;
+    int64_t batch, m, n, k;
+    float ms;
+} mssr_prof_record;
+int mssr_prof_start(int max_records);
+int mssr_prof_stop(void);                       /* waits for the device; returns the record count */
+int mssr_prof_get(int i, mssr_prof_record* out);
 
 /* --------------------------------------------------------------------- row softmax --------
  * y = softmax(scale * x) along the last axis, optionally masked, optionally log-softmax.
@@ -186,6 +210,9 @@ typedef struct {
     int Ls, T;                    /* source (memory) length, number of decode steps */
     int save;                     /* 1: keep per-step activations for mssr_decode_step_bwd */
     int training;                 /* 1: dropout active (p_drop residual/FFN/embedding, p_attn attention) */
+    int n_chunks;                 /* 1..8: the batch is cut into this many row chunks whose (independent)
+                                   * dependency chains run on concurrent internal streams forked from / joined
+                                   * into the caller's stream; dropout masks depend on the chunking */
     float p_drop, p_attn, temperature;
     uint64_t seed;
     const mssr_dec_layer* layers; /* host array [n_layers] */

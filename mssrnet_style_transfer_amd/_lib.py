@@ -28,7 +28,8 @@ class GemmDesc(Structure):
                 ("alpha", c_float), ("beta", c_float), ("relu", c_int),
                 ("in_dtype", c_int), ("out_dtype", c_int),
                 ("drop_p", c_float), ("drop_seed", c_uint64),
-                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("no_skinny", c_int)]
+                ("workspace", c_void_p), ("workspace_bytes", c_int64), ("no_skinny", c_int),
+                ("ln_colsum", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_eps", c_float)]
 
 
 class DecLayer(Structure):
@@ -42,7 +43,7 @@ class DecLayer(Structure):
 class DecodePlan(Structure):
     """mssr_decode_plan (include/mssr_hip.h)."""
     _fields_ = ([(n, c_int) for n in ("dtype", "B", "d", "heads", "ff", "n_layers", "V", "Vp", "Ls", "T", "save",
-                                      "training")]
+                                      "training", "n_chunks")]
                 + [("p_drop", c_float), ("p_attn", c_float), ("temperature", c_float), ("seed", c_uint64),
                    ("layers", POINTER(DecLayer))]
                 + [(n, c_void_p) for n in ("emb_t", "emb", "pe", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b",
@@ -51,6 +52,12 @@ class DecodePlan(Structure):
                 + [("gemm_ws_bytes", c_int64)]
                 + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dkv_acc",
                                            "dmem_acc", "d_e", "dnf")])
+
+
+class ProfRecord(Structure):
+    """mssr_prof_record (include/mssr_hip.h)."""
+    _fields_ = [("kernel", c_int), ("in_dtype", c_int), ("out_dtype", c_int), ("tile", c_int),
+                ("batch", c_int64), ("m", c_int64), ("n", c_int64), ("k", c_int64), ("ms", c_float)]
 
 
 _P, _I, _L, _F, _U = c_void_p, c_int, c_int64, c_float, c_uint64
@@ -75,6 +82,9 @@ SIGNATURES = {
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
     "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),
+    "mssr_prof_start": ([_I], c_int),
+    "mssr_prof_stop": ([], c_int),
+    "mssr_prof_get": ([_I, POINTER(ProfRecord)], c_int),
     "mssr_decode_step_fwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_step_bwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_fwd": ([POINTER(DecodePlan), _P], c_int),

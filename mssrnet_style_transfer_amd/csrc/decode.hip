@@ -12,10 +12,12 @@
 // gradient of every GEMM output in a slab and the caller contracts each slab once at the end
 // (dW = dY_all^T X_all with a long reduction dimension instead of 28 products of depth 80).
 #include "common.hpp"
+#include <thread>
 
 namespace mssr {
 
-constexpr int AT_MAXK = 512;    // keys per (b, h) the step-attention kernels handle
+constexpr int AT_MAXK = 512; 
+constexpr int MAX_CHUNKS = 8;      // concurrent batch chunks (streams) of one decode   // keys per (b, h) the step-attention kernels handle
 
 // ------------------------------------------------------------------ single-query attention
 // One wave64 per (batch, head).  q [dh], keys/values addressed with strides, optional pad mask.
@@ -300,11 +302,17 @@ __global__ __launch_bounds__(256) void vocab_softmax_kernel(const T* __restrict_
     }
 }
 
+// One chunk of the batch (rows b0 .. b0+Bc of every [B, .] slab) on its own stream: sentences are
+// independent, every kernel of a decode step is latency-bound and fills a fraction of the 256 CUs,
+// so the engine runs several chunks' dependency chains concurrently.
 struct Ctx {
     const mssr_decode_plan* p;
     hipStream_t s;
     int dt;
     size_t es;      // element size of the compute dtype
+    int b0, Bc, chunk;
+    void* ws;       // this chunk's split-K workspace
+    int64_t ws_bytes;
 };
 
 static inline char* at(void* base, int64_t elems, size_t es) { return (char*)base + elems * (int64_t)es; }
@@ -323,12 +331,14 @@ static int gemm_nt(const Ctx& c, const void* a, int64_t lda, const void* w, int6
     d.alpha = alpha; d.beta = beta; d.relu = relu;
     d.in_dtype = c.dt; d.out_dtype = out_dt;
     d.drop_p = drop_p; d.drop_seed = seed;
-    d.workspace = c.p->gemm_ws; d.workspace_bytes = c.p->gemm_ws_bytes; d.no_skinny = 0;
+    d.workspace = c.ws; d.workspace_bytes = c.ws_bytes; d.no_skinny = 0;
+    d.ln_colsum = nullptr; d.ln_mean = nullptr; d.ln_rstd = nullptr; d.ln_eps = 0.f;
     return mssr_gemm(&d, c.s);
 }
 
-static inline uint64_t site_seed(const mssr_decode_plan* p, int step, int layer, int site) {
-    return p->seed + (uint64_t)step * 0x100000001B3ull + (uint64_t)(layer + 1) * 0x9E3779B1ull + (uint64_t)site * 7919ull;
+static inline uint64_t site_seed(const Ctx& c, int step, int layer, int site) {
+    return c.p->seed + (uint64_t)step * 0x100000001B3ull + (uint64_t)(layer + 1) * 0x9E3779B1ull +
+           (uint64_t)site * 7919ull + (uint64_t)c.chunk * 0xC2B2AE3D27D4EB4Full;
 }
 
 template <typename T>
@@ -337,9 +347,9 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
                             float p_drop, uint64_t seed) {
     const mssr_decode_plan* p = c.p;
     const int dh = p->d / p->heads;
-    const int bh = p->B * p->heads;
+    const int bh = c.Bc * p->heads;
     attn_step_fwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
-        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, p->B, p->heads, dh,
+        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh,
         Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
 }
 
@@ -351,10 +361,10 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
                             uint64_t seed) {
     const mssr_decode_plan* p = c.p;
     const int dh = p->d / p->heads;
-    const int bh = p->B * p->heads;
+    const int bh = c.Bc * p->heads;
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
-        dq_bs, dk_acc, dv_acc, acc_bs, acc_ts, fin_row, (T*)dk_out, (T*)dv_out, out_bs, p->B, p->heads, dh, Lk,
+        dq_bs, dk_acc, dv_acc, acc_bs, acc_ts, fin_row, (T*)dk_out, (T*)dv_out, out_bs, c.Bc, p->heads, dh, Lk,
         1.0f / sqrtf((float)dh), p_drop, seed);
 }
 
@@ -380,13 +390,10 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
                      p->nf && p->logits && p->tmp,
                  "%s: null buffer in plan", who);
     MSSR_REQUIRE(p->temperature > 0.f, "%s: temperature must be positive", who);
+    MSSR_REQUIRE(p->n_chunks >= 1 && p->n_chunks <= MAX_CHUNKS, "%s: n_chunks must be in [1, %d]", who, MAX_CHUNKS);
     MSSR_REQUIRE(p->p_drop >= 0.f && p->p_drop < 1.f && p->p_attn >= 0.f && p->p_attn < 1.f, "%s: bad dropout", who);
     return MSSR_OK;
 }
-
-}  // namespace mssr
-
-using namespace mssr;
 
 // Slab geometry (elements), shared by forward and backward.  Ts = save ? T : 1, slot = save ? step : 0.
 //   X     [n_layers+1][Ts][B,d]      residual stream entering layer l (l = n_layers: decoder output)
@@ -400,94 +407,113 @@ using namespace mssr;
 enum { K_N1 = 0, K_CTX1, K_H1, K_N2, K_QC, K_CTX2, K_H2, K_N3, K_NKINDS };
 enum { G_DN1 = 0, G_DSO, G_DN2, G_DCQ, G_DCO, G_DN3, G_DF2, G_NKINDS };
 
-#define ENGINE_GEOMETRY(p, step)                                                    \
-    const int B = (p)->B, d = (p)->d, ff = (p)->ff, NL = (p)->n_layers;             \
-    const int Ts = (p)->save ? (p)->T : 1;                                          \
-    const int slot = (p)->save ? (step) : 0;                                        \
-    const int64_t Bd = (int64_t)B * d;                                              \
-    (void)ff; (void)NL; (void)Ts; (void)slot; (void)Bd;
+// A step block of a slab holds B rows; this chunk owns rows r0 .. r0+R of it.
+struct Geo {
+    int B, R, r0, d, ff, NL, T, Ts, slot, V, Vp, Ls;
+    size_t es;
+    const mssr_decode_plan* p;
+    Geo(const Ctx& c, int step)
+        : B(c.p->B), R(c.Bc), r0(c.b0), d(c.p->d), ff(c.p->ff), NL(c.p->n_layers), T(c.p->T),
+          Ts(c.p->save ? c.p->T : 1), slot(c.p->save ? step : 0), V(c.p->V), Vp(c.p->Vp), Ls(c.p->Ls), es(c.es),
+          p(c.p) {}
+    // rows of block `blk` of a slab whose rows are `w` elements wide
+    char* rows(void* base, int64_t blk, int64_t w) const { return at(base, (blk * B + r0) * w, es); }
+    char* X(int l) const { return rows(p->X, (int64_t)l * Ts + slot, d); }
+    char* act(int l, int kind) const { return rows(p->actD, ((int64_t)l * K_NKINDS + kind) * Ts + slot, d); }
+    char* inter(int l) const { return rows(p->actF, (int64_t)l * Ts + slot, ff); }
+    float* stat(int idx, int which) const { return p->stats + (((int64_t)idx * 2 + which) * Ts + slot) * B + r0; }
+    char* qkv(int l, int step) const { return rows(p->qkv, (int64_t)l * T + step, 3 * d); }
+    char* dact(int l, int kind, int step) const { return rows(p->dactD, ((int64_t)l * G_NKINDS + kind) * T + step, d); }
+    char* dinter(int l, int step) const { return rows(p->dactF, (int64_t)l * T + step, ff); }
+    char* dqkv(int l, int step) const { return rows(p->dqkv, (int64_t)l * T + step, 3 * d); }
+    float* kv_acc(int l) const { return p->dkv_acc + ((int64_t)l * T * B + r0) * 2 * d; }          // step 0 block
+    const char* mem_kv(int l) const { return at((void*)p->mem_kv, ((int64_t)r0 * Ls * NL + l) * 2 * d, es); }
+    float* mem_acc(int l) const { return p->dmem_acc + ((int64_t)r0 * Ls * NL + l) * 2 * d; }
+    const uint8_t* src_mask() const { return p->src_mask + (int64_t)r0 * Ls; }
+    char* tmp() const { return at(p->tmp, (int64_t)r0 * d, es); }
+    char* logits() const { return at(p->logits, (int64_t)r0 * Vp, es); }
+    char* dX() const { return at(p->dX, (int64_t)r0 * d, es); }
+};
 
-extern "C" int mssr_decode_step_fwd(const mssr_decode_plan* p, int step, void* stream) {
-    if (int e = check_plan(p, step, "decode_step_fwd")) return e;
-    Ctx c{p, (hipStream_t)stream, p->dtype, dsize(p->dtype)};
-    ENGINE_GEOMETRY(p, step);
+static int step_fwd(const Ctx& c, int step) {
+    const mssr_decode_plan* p = c.p;
+    const Geo G(c, step);
+    const int B = G.B, R = G.R, d = G.d, ff = G.ff, NL = G.NL;
     const size_t es = c.es;
+    const int64_t Rd = (int64_t)R * d;
     const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
     int rc;
-    auto Xl = [&](int l) { return at(p->X, ((int64_t)l * Ts + slot) * Bd, es); };
-    auto ACT = [&](int l, int kind) { return at(p->actD, (((int64_t)l * K_NKINDS + kind) * Ts + slot) * Bd, es); };
-    auto ST = [&](int idx, int which) { return p->stats + (((int64_t)idx * 2 + which) * Ts + slot) * B; };
-
     // embedding of the (soft) input: e = in[step] . E ; x0 = dropout(e*sqrt(d) + pe[step])
-    const void* in = at(p->in_all, (int64_t)step * B * p->Vp, es);
-    if ((rc = gemm_nt(c, in, p->Vp, p->emb_t, p->Vp, p->tmp, d, B, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
+    const void* in = G.rows(p->in_all, step, p->Vp);
+    if ((rc = gemm_nt(c, in, p->Vp, p->emb_t, p->Vp, G.tmp(), d, R, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                       0.f, c.dt, 0.f, 0)))
         return rc;
     {
-        const unsigned g = (unsigned)((Bd / 4 + 255) / 256);
+        const unsigned g = (unsigned)((Rd / 4 + 255) / 256);
         if (c.dt == MSSR_F32)
-            embed_epilogue_kernel<float><<<g, 256, 0, c.s>>>((const float*)p->tmp, p->pe, (float*)Xl(0), B, d, step,
-                                                             sqrtf((float)d), pd, site_seed(p, step, -1, 0));
+            embed_epilogue_kernel<float><<<g, 256, 0, c.s>>>((const float*)G.tmp(), p->pe, (float*)G.X(0), R, d, step,
+                                                             sqrtf((float)d), pd, site_seed(c, step, -1, 0));
         else
-            embed_epilogue_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)p->tmp, p->pe, (bf16*)Xl(0), B, d, step,
-                                                            sqrtf((float)d), pd, site_seed(p, step, -1, 0));
+            embed_epilogue_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)G.tmp(), p->pe, (bf16*)G.X(0), R, d, step,
+                                                            sqrtf((float)d), pd, site_seed(c, step, -1, 0));
     }
     for (int l = 0; l < NL; ++l) {
         const mssr_dec_layer& L = p->layers[l];
-        char* x = Xl(l);
-        char *n1 = ACT(l, K_N1), *ctx1 = ACT(l, K_CTX1), *h1 = ACT(l, K_H1), *n2 = ACT(l, K_N2), *qc = ACT(l, K_QC),
-             *ctx2 = ACT(l, K_CTX2), *h2 = ACT(l, K_H2), *n3 = ACT(l, K_N3);
-        char* inter = at(p->actF, ((int64_t)l * Ts + slot) * B * ff, es);
-        char* qkv_l = at(p->qkv, (int64_t)l * p->T * B * 3 * d, es);            // [T][B,3d]
-        char* qkv_s = qkv_l + (int64_t)step * B * 3 * d * es;
+        char* x = G.X(l);
+        char *n1 = G.act(l, K_N1), *ctx1 = G.act(l, K_CTX1), *h1 = G.act(l, K_H1), *n2 = G.act(l, K_N2),
+             *qc = G.act(l, K_QC), *ctx2 = G.act(l, K_CTX2), *h2 = G.act(l, K_H2), *n3 = G.act(l, K_N3);
+        char* inter = G.inter(l);
+        char* qkv_0 = G.qkv(l, 0);               // this chunk's rows of step 0: the cache base
+        char* qkv_s = G.qkv(l, step);
         // --- self attention block
-        if ((rc = mssr_layernorm_fwd(x, L.ln1_g, L.ln1_b, n1, ST(l * 3 + 0, 0), ST(l * 3 + 0, 1), B, d, 1e-6f, c.dt,
-                                     c.s)))
+        if ((rc = mssr_layernorm_fwd(x, L.ln1_g, L.ln1_b, n1, G.stat(l * 3 + 0, 0), G.stat(l * 3 + 0, 1), R, d, 1e-6f,
+                                     c.dt, c.s)))
             return rc;
-        if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, 3 * d, B, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f, 0.f,
+        if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, 3 * d, R, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f, 0.f,
                           c.dt, 0.f, 0)))
             return rc;
-        DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_l + (int64_t)d * es, qkv_l + 2LL * d * es, 3 * d,
-                (int64_t)B * 3 * d, nullptr, 0, ctx1, d, step + 1, pa, site_seed(p, step, l, 1));
-        if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, B, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          site_seed(p, step, l, 2))))
+        DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
+                (int64_t)B * 3 * d, nullptr, 0, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
+        if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, R, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
+                          site_seed(c, step, l, 2))))
             return rc;
         // --- context attention block (keys / values of the memory bank were projected once)
-        if ((rc = mssr_layernorm_fwd(h1, L.ln2_g, L.ln2_b, n2, ST(l * 3 + 1, 0), ST(l * 3 + 1, 1), B, d, 1e-6f, c.dt,
-                                     c.s)))
+        if ((rc = mssr_layernorm_fwd(h1, L.ln2_g, L.ln2_b, n2, G.stat(l * 3 + 1, 0), G.stat(l * 3 + 1, 1), R, d, 1e-6f,
+                                     c.dt, c.s)))
             return rc;
-        if ((rc = gemm_nt(c, n2, d, L.w_cq, d, qc, d, B, d, d, L.b_cq, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, 0.f,
+        if ((rc = gemm_nt(c, n2, d, L.w_cq, d, qc, d, R, d, d, L.b_cq, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, 0.f,
                           0)))
             return rc;
-        const char* mkv = at((void*)p->mem_kv, (int64_t)l * 2 * d, es);         // [B, Ls, NL, 2d], layer l
+        const char* mkv = G.mem_kv(l);                                      // [B, Ls, NL, 2d], layer l
         DT_CALL(c, launch_attn_fwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
-                (int64_t)NL * 2 * d, p->src_mask, p->Ls, ctx2, d, p->Ls, pa, site_seed(p, step, l, 3));
-        if ((rc = gemm_nt(c, ctx2, d, L.w_co, d, h2, d, B, d, d, L.b_co, 0, h1, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          site_seed(p, step, l, 4))))
+                (int64_t)NL * 2 * d, G.src_mask(), p->Ls, ctx2, d, p->Ls, pa, site_seed(c, step, l, 3));
+        if ((rc = gemm_nt(c, ctx2, d, L.w_co, d, h2, d, R, d, d, L.b_co, 0, h1, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
+                          site_seed(c, step, l, 4))))
             return rc;
         // --- feed forward block
-        if ((rc = mssr_layernorm_fwd(h2, L.lnf_g, L.lnf_b, n3, ST(l * 3 + 2, 0), ST(l * 3 + 2, 1), B, d, 1e-6f, c.dt,
-                                     c.s)))
+        if ((rc = mssr_layernorm_fwd(h2, L.lnf_g, L.lnf_b, n3, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1), R, d, 1e-6f,
+                                     c.dt, c.s)))
             return rc;
-        if ((rc = gemm_nt(c, n3, d, L.w_1, d, inter, ff, B, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          site_seed(p, step, l, 5))))
+        if ((rc = gemm_nt(c, n3, d, L.w_1, d, inter, ff, R, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, pd,
+                          site_seed(c, step, l, 5))))
             return rc;
-        if ((rc = gemm_nt(c, inter, ff, L.w_2, ff, Xl(l + 1), d, B, d, ff, L.b_2, 0, h2, d, nullptr, 0, 1.f, 0.f, c.dt,
-                          pd, site_seed(p, step, l, 6))))
+        if ((rc = gemm_nt(c, inter, ff, L.w_2, ff, G.X(l + 1), d, R, d, ff, L.b_2, 0, h2, d, nullptr, 0, 1.f, 0.f, c.dt,
+                          pd, site_seed(c, step, l, 6))))
             return rc;
     }
     // final LayerNorm, generator Linear, softmax(/T)
-    char* nf = at(p->nf, (int64_t)slot * Bd, es);
-    if ((rc = mssr_layernorm_fwd(Xl(NL), p->lnF_g, p->lnF_b, nf, ST(NL * 3, 0), ST(NL * 3, 1), B, d, 1e-6f, c.dt, c.s)))
+    char* nf = G.rows(p->nf, G.slot, d);
+    if ((rc = mssr_layernorm_fwd(G.X(NL), p->lnF_g, p->lnF_b, nf, G.stat(NL * 3, 0), G.stat(NL * 3, 1), R, d, 1e-6f,
+                                 c.dt, c.s)))
         return rc;
-    if ((rc = gemm_nt(c, nf, d, p->w_gen, d, p->logits, p->Vp, B, p->V, d, p->b_gen, 0, nullptr, 0, nullptr, 0, 1.f,
+    if ((rc = gemm_nt(c, nf, d, p->w_gen, d, G.logits(), p->Vp, R, p->V, d, p->b_gen, 0, nullptr, 0, nullptr, 0, 1.f,
                       0.f, c.dt, 0.f, 0)))
         return rc;
-    float* probs = p->probs + (int64_t)step * B * p->V;
-    void* copy = at(p->in_all, (int64_t)(step + 1) * B * p->Vp, es);      // in_all has T+1 slots
+    float* probs = p->probs + ((int64_t)step * B + G.r0) * p->V;
+    void* copy = G.rows(p->in_all, step + 1, p->Vp);                        // in_all has T+1 slots
     const int ne = (p->V + 255) / 256;
-#define VS(T, NEc)                                                                                          \
-    vocab_softmax_kernel<T, NEc><<<B, 256, 0, c.s>>>((const T*)p->logits, p->Vp, probs, p->V, (T*)copy, p->Vp, \
+#define VS(T, NEc)                                                                                             \
+    vocab_softmax_kernel<T, NEc><<<R, 256, 0, c.s>>>((const T*)G.logits(), p->Vp, probs, p->V, (T*)copy, p->Vp, \
                                                      p->V, 1.0f / p->temperature)
     if (c.dt == MSSR_F32) {
         if (ne <= 8) VS(float, 8); else if (ne <= 16) VS(float, 16); else if (ne <= 40) VS(float, 40); else VS(float, 64);
@@ -498,24 +524,17 @@ extern "C" int mssr_decode_step_fwd(const mssr_decode_plan* p, int step, void* s
     MSSR_LAUNCH_OK("decode_step_fwd");
 }
 
-extern "C" int mssr_decode_step_bwd(const mssr_decode_plan* p, int step, void* stream) {
-    if (int e = check_plan(p, step, "decode_step_bwd")) return e;
-    MSSR_REQUIRE(p->save, "decode_step_bwd: the forward did not save activations (save = 0)");
-    MSSR_REQUIRE(p->emb && p->wt_gen && p->dprobs && p->dlogits && p->dX && p->dqkv && p->dactD && p->dactF &&
-                     p->dkv_acc && p->dmem_acc && p->d_e && p->dnf,
-                 "decode_step_bwd: null gradient buffer in plan");
-    Ctx c{p, (hipStream_t)stream, p->dtype, dsize(p->dtype)};
-    ENGINE_GEOMETRY(p, step);
+static int step_bwd(const Ctx& c, int step) {
+    const mssr_decode_plan* p = c.p;
+    const Geo G(c, step);
+    const int B = G.B, R = G.R, d = G.d, ff = G.ff, NL = G.NL;
     const size_t es = c.es;
+    const int64_t Rd = (int64_t)R * d;
     const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
     const float keep = pd > 0.f ? 1.0f / (1.0f - pd) : 1.0f;
     int rc;
-    auto Xl = [&](int l) { return at(p->X, ((int64_t)l * Ts + slot) * Bd, es); };
-    auto ACT = [&](int l, int kind) { return at(p->actD, (((int64_t)l * K_NKINDS + kind) * Ts + slot) * Bd, es); };
-    auto ST = [&](int idx, int which) { return p->stats + (((int64_t)idx * 2 + which) * Ts + slot) * B; };
     // gradient slabs: dactD [n_layers][7][T][B,d] = dn1 | d_so | dn2 | d_cq | d_co | dn3 | d_f2 (gradients of the
     // outputs of LN1, self out-proj, LN2, ctx query proj, ctx out-proj, LN3, W2); dactF [n_layers][T][B,ff] = d_f1
-    auto DACT = [&](int l, int kind) { return at(p->dactD, (((int64_t)l * G_NKINDS + kind) * p->T + step) * Bd, es); };
     auto drop_replay = [&](const void* x, void* y, int64_t n, uint64_t seed, float extra) {
         const unsigned g = (unsigned)((n / 4 + 255) / 256);
         if (c.dt == MSSR_F32) drop_replay_kernel<float><<<g, 256, 0, c.s>>>((const float*)x, (float*)y, n, pd, seed, extra);
@@ -523,112 +542,223 @@ extern "C" int mssr_decode_step_bwd(const mssr_decode_plan* p, int step, void* s
     };
     auto ln_bwd = [&](const void* dy, const void* x, const float* g, int idx, const void* dres, void* dx) {
         if (c.dt == MSSR_F32)
-            ln_bwd_dx_kernel<float><<<(B + 3) / 4, 256, 0, c.s>>>((const float*)dy, (const float*)x, g, ST(idx, 0),
-                                                                 ST(idx, 1), (const float*)dres, (float*)dx, B, d);
+            ln_bwd_dx_kernel<float><<<(R + 3) / 4, 256, 0, c.s>>>((const float*)dy, (const float*)x, g, G.stat(idx, 0),
+                                                                 G.stat(idx, 1), (const float*)dres, (float*)dx, R, d);
         else
-            ln_bwd_dx_kernel<bf16><<<(B + 3) / 4, 256, 0, c.s>>>((const bf16*)dy, (const bf16*)x, g, ST(idx, 0),
-                                                                ST(idx, 1), (const bf16*)dres, (bf16*)dx, B, d);
+            ln_bwd_dx_kernel<bf16><<<(R + 3) / 4, 256, 0, c.s>>>((const bf16*)dy, (const bf16*)x, g, G.stat(idx, 0),
+                                                                G.stat(idx, 1), (const bf16*)dres, (bf16*)dx, R, d);
     };
 
     // softmax backward: dlogits[step] (compute dtype, padded columns stay zero)
-    char* dlg = at(p->dlogits, (int64_t)step * B * p->Vp, es);
-    const float* probs = p->probs + (int64_t)step * B * p->V;
-    const float* dpr = p->dprobs + (int64_t)step * B * p->V;
-    if ((rc = mssr_softmax_bwd(probs, dpr, dlg, B, p->V, p->V, p->V, p->Vp, 1.0f / p->temperature, 0, MSSR_F32,
+    char* dlg = G.rows(p->dlogits, step, p->Vp);
+    const float* probs = p->probs + ((int64_t)step * B + G.r0) * p->V;
+    const float* dpr = p->dprobs + ((int64_t)step * B + G.r0) * p->V;
+    if ((rc = mssr_softmax_bwd(probs, dpr, dlg, R, p->V, p->V, p->V, p->Vp, 1.0f / p->temperature, 0, MSSR_F32,
                                MSSR_F32, c.dt, c.s)))
         return rc;
     // generator Linear: dnf = dlogits . W_gen   (W as [N=d, K=Vp] = wt_gen)
-    char* dnf = at(p->dnf, (int64_t)step * Bd, es);
-    if ((rc = gemm_nt(c, dlg, p->Vp, p->wt_gen, p->Vp, dnf, d, B, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
+    char* dnf = G.rows(p->dnf, step, d);
+    if ((rc = gemm_nt(c, dlg, p->Vp, p->wt_gen, p->Vp, dnf, d, R, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                       0.f, c.dt, 0.f, 0)))
         return rc;
-    char* dx = (char*)p->dX;                   // running gradient of the residual stream [B,d]
-    ln_bwd(dnf, Xl(NL), p->lnF_g, NL * 3, nullptr, dx);
+    char* dx = G.dX();                         // running gradient of the residual stream [R,d]
+    char* tmp = G.tmp();
+    ln_bwd(dnf, G.X(NL), p->lnF_g, NL * 3, nullptr, dx);
     for (int l = NL - 1; l >= 0; --l) {
         const mssr_dec_layer& L = p->layers[l];
-        char *h1 = ACT(l, K_H1), *qc = ACT(l, K_QC), *h2 = ACT(l, K_H2);
-        char* inter = at(p->actF, ((int64_t)l * Ts + slot) * B * ff, es);
-        char *dn1 = DACT(l, G_DN1), *d_so = DACT(l, G_DSO), *dn2 = DACT(l, G_DN2), *d_cq = DACT(l, G_DCQ),
-             *d_co = DACT(l, G_DCO), *dn3 = DACT(l, G_DN3), *d_f2 = DACT(l, G_DF2);
-        char* d_f1 = at(p->dactF, ((int64_t)l * p->T + step) * B * ff, es);
-        char* qkv_l = at(p->qkv, (int64_t)l * p->T * B * 3 * d, es);
-        char* qkv_s = qkv_l + (int64_t)step * B * 3 * d * es;
-        char* dqkv_s = at(p->dqkv, ((int64_t)l * p->T + step) * B * 3 * d, es);
+        char *h1 = G.act(l, K_H1), *qc = G.act(l, K_QC), *h2 = G.act(l, K_H2);
+        char* inter = G.inter(l);
+        char *dn1 = G.dact(l, G_DN1, step), *d_so = G.dact(l, G_DSO, step), *dn2 = G.dact(l, G_DN2, step),
+             *d_cq = G.dact(l, G_DCQ, step), *d_co = G.dact(l, G_DCO, step), *dn3 = G.dact(l, G_DN3, step),
+             *d_f2 = G.dact(l, G_DF2, step);
+        char* d_f1 = G.dinter(l, step);
+        char* qkv_0 = G.qkv(l, 0);
+        char* qkv_s = G.qkv(l, step);
+        char* dqkv_s = G.dqkv(l, step);
         // --- feed forward block: y = h2 + drop(W2 inter + b2), inter = drop(relu(W1 n3 + b1))
-        if (pd > 0.f) drop_replay(dx, d_f2, Bd, site_seed(p, step, l, 6), 1.f);
-        else (void)hipMemcpyAsync(d_f2, dx, Bd * es, hipMemcpyDeviceToDevice, c.s);
+        if (pd > 0.f) drop_replay(dx, d_f2, Rd, site_seed(c, step, l, 6), 1.f);
+        else (void)hipMemcpyAsync(d_f2, dx, Rd * es, hipMemcpyDeviceToDevice, c.s);
         // d_f1 = (d_f2 . W2) * (inter > 0) / (1-p)      [W as [N=ff, K=d] = wt_2]
-        if ((rc = gemm_nt(c, d_f2, d, L.wt_2, d, d_f1, ff, B, ff, d, nullptr, 0, nullptr, 0, inter, ff, keep, 0.f, c.dt,
+        if ((rc = gemm_nt(c, d_f2, d, L.wt_2, d, d_f1, ff, R, ff, d, nullptr, 0, nullptr, 0, inter, ff, keep, 0.f, c.dt,
                           0.f, 0)))
             return rc;
-        if ((rc = gemm_nt(c, d_f1, ff, L.wt_1, ff, dn3, d, B, d, ff, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+        if ((rc = gemm_nt(c, d_f1, ff, L.wt_1, ff, dn3, d, R, d, ff, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;
         ln_bwd(dn3, h2, L.lnf_g, l * 3 + 2, dx, dx);                     // dx <- grad wrt h2
         // --- context attention block: h2 = h1 + drop(Wco ctx2 + bco)
-        if (pd > 0.f) drop_replay(dx, d_co, Bd, site_seed(p, step, l, 4), 1.f);
-        else (void)hipMemcpyAsync(d_co, dx, Bd * es, hipMemcpyDeviceToDevice, c.s);
-        if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, p->tmp, d, B, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+        if (pd > 0.f) drop_replay(dx, d_co, Rd, site_seed(c, step, l, 4), 1.f);
+        else (void)hipMemcpyAsync(d_co, dx, Rd * es, hipMemcpyDeviceToDevice, c.s);
+        if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, tmp, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;                                                    // tmp = dctx2
         {
-            const char* mkv = at((void*)p->mem_kv, (int64_t)l * 2 * d, es);
-            float* macc = p->dmem_acc + (int64_t)l * 2 * d;                // [B, Ls, NL, 2d] float, layer l
+            const char* mkv = G.mem_kv(l);
+            float* macc = G.mem_acc(l);                                   // [B, Ls, NL, 2d] float, layer l
             DT_CALL(c, launch_attn_bwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
-                    (int64_t)NL * 2 * d, p->src_mask, p->Ls, p->tmp, d, d_cq, d, macc, macc + d,
+                    (int64_t)NL * 2 * d, G.src_mask(), p->Ls, tmp, d, d_cq, d, macc, macc + d,
                     (int64_t)p->Ls * NL * 2 * d, (int64_t)NL * 2 * d, -1, nullptr, nullptr, 0, p->Ls, pa,
-                    site_seed(p, step, l, 3));
+                    site_seed(c, step, l, 3));
         }
-        if ((rc = gemm_nt(c, d_cq, d, L.wt_cq, d, dn2, d, B, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+        if ((rc = gemm_nt(c, d_cq, d, L.wt_cq, d, dn2, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;
         ln_bwd(dn2, h1, L.ln2_g, l * 3 + 1, dx, dx);                     // dx <- grad wrt h1
         // --- self attention block: h1 = x + drop(Wso ctx1 + bso)
-        if (pd > 0.f) drop_replay(dx, d_so, Bd, site_seed(p, step, l, 2), 1.f);
-        else (void)hipMemcpyAsync(d_so, dx, Bd * es, hipMemcpyDeviceToDevice, c.s);
-        if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, p->tmp, d, B, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+        if (pd > 0.f) drop_replay(dx, d_so, Rd, site_seed(c, step, l, 2), 1.f);
+        else (void)hipMemcpyAsync(d_so, dx, Rd * es, hipMemcpyDeviceToDevice, c.s);
+        if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, tmp, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;                                                    // tmp = dctx1
         {
-            float* kacc = p->dkv_acc + (int64_t)l * p->T * B * 2 * d;      // [T][B, 2d] float
-            DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_l + (int64_t)d * es, qkv_l + 2LL * d * es, 3 * d,
-                    (int64_t)B * 3 * d, nullptr, 0, p->tmp, d, dqkv_s, 3 * d, kacc, kacc + d, 2 * d, (int64_t)B * 2 * d,
+            float* kacc = G.kv_acc(l);                                    // [T][B, 2d] float
+            DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
+                    (int64_t)B * 3 * d, nullptr, 0, tmp, d, dqkv_s, 3 * d, kacc, kacc + d, 2 * d, (int64_t)B * 2 * d,
                     step, dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa,
-                    site_seed(p, step, l, 1));
+                    site_seed(c, step, l, 1));
         }
-        if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, B, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
+        if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))
             return rc;
-        ln_bwd(dn1, Xl(l), L.ln1_g, l * 3 + 0, dx, dx);                  // dx <- grad wrt layer input
+        ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dx, dx);                 // dx <- grad wrt layer input
     }
     // embedding: x0 = drop(e*sqrt(d) + pe)  ->  d_e ; feedback into the previous step's probabilities
-    char* de = at(p->d_e, (int64_t)step * Bd, es);
-    if (pd > 0.f) drop_replay(dx, de, Bd, site_seed(p, step, -1, 0), sqrtf((float)d));
+    char* de = G.rows(p->d_e, step, d);
+    if (pd > 0.f) drop_replay(dx, de, Rd, site_seed(c, step, -1, 0), sqrtf((float)d));
     else {
-        if ((rc = mssr_axpby(dx, nullptr, de, Bd, sqrtf((float)d), 0.f, c.dt, c.s))) return rc;
+        if ((rc = mssr_axpby(dx, nullptr, de, Rd, sqrtf((float)d), 0.f, c.dt, c.s))) return rc;
     }
     if (step > 0) {
-        float* dprev = p->dprobs + (int64_t)(step - 1) * B * p->V;
+        float* dprev = p->dprobs + ((int64_t)(step - 1) * B + G.r0) * p->V;
         // dprobs[step-1] += d_e . E^T      (W as [N=V, K=d] = E itself)
-        if ((rc = gemm_nt(c, de, d, p->emb, d, dprev, p->V, B, p->V, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 1.f,
+        if ((rc = gemm_nt(c, de, d, p->emb, d, dprev, p->V, R, p->V, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 1.f,
                           MSSR_F32, 0.f, 0)))
             return rc;
     }
     MSSR_LAUNCH_OK("decode_step_bwd");
 }
 
+// ---- chunk streams: created once per device, reused by every decode
+struct StreamPool {
+    bool ready = false;
+    hipStream_t s[MAX_CHUNKS];
+    hipEvent_t fork, join[MAX_CHUNKS];
+};
+static StreamPool g_pools[16];
+
+static StreamPool* pool_for_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    StreamPool& P = g_pools[dev];
+    if (!P.ready) {
+        for (int i = 0; i < MAX_CHUNKS; ++i) {
+            if (hipStreamCreateWithFlags(&P.s[i], hipStreamNonBlocking) != hipSuccess) return nullptr;
+            if (hipEventCreateWithFlags(&P.join[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        }
+        if (hipEventCreateWithFlags(&P.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+        P.ready = true;
+    }
+    return &P;
+}
+
+// Runs steps [s_begin, s_end) (forward) or the same range downwards (backward) for every chunk.
+static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool backward, hipStream_t stream,
+                     const char* who) {
+    if (int e = check_plan(p, s_begin, who)) return e;
+    MSSR_REQUIRE(s_end > s_begin && s_end <= p->T, "%s: bad step range", who);
+    if (backward) {
+        MSSR_REQUIRE(p->save, "%s: the forward did not save activations (save = 0)", who);
+        MSSR_REQUIRE(p->emb && p->wt_gen && p->dprobs && p->dlogits && p->dX && p->dqkv && p->dactD && p->dactF &&
+                         p->dkv_acc && p->dmem_acc && p->d_e && p->dnf,
+                     "%s: null gradient buffer in plan", who);
+    }
+    const int per = (p->B + p->n_chunks - 1) / p->n_chunks;
+    const int nch = (p->B + per - 1) / per;
+    Ctx cs[MAX_CHUNKS];
+    StreamPool* P = nullptr;
+    if (nch > 1) {
+        P = pool_for_current_device();
+        MSSR_REQUIRE(P, "%s: could not create the chunk streams", who);
+        if (hipEventRecord(P->fork, stream) != hipSuccess) { set_error("%s: fork failed", who); return MSSR_ERR_LAUNCH; }
+    }
+    const int64_t ws_each = p->gemm_ws ? (p->gemm_ws_bytes / nch) & ~(int64_t)255 : 0;
+    for (int i = 0; i < nch; ++i) {
+        Ctx& c = cs[i];
+        c.p = p; c.dt = p->dtype; c.es = dsize(p->dtype);
+        c.b0 = i * per; c.Bc = (c.b0 + per <= p->B) ? per : p->B - c.b0; c.chunk = i;
+        c.ws = p->gemm_ws ? (char*)p->gemm_ws + i * ws_each : nullptr;
+        c.ws_bytes = ws_each;
+        c.s = stream;
+        if (nch > 1) {
+            c.s = P->s[i];
+            (void)hipStreamWaitEvent(c.s, P->fork, 0);
+        }
+    }
+    int rc = MSSR_OK;
+    auto run_chunk = [&](int i) -> int {
+        int r = MSSR_OK;
+        for (int k = 0; k < s_end - s_begin && r == MSSR_OK; ++k) {
+            const int step = backward ? s_end - 1 - k : s_begin + k;
+            r = backward ? step_bwd(cs[i], step) : step_fwd(cs[i], step);
+        }
+        return r;
+    };
+    if (nch == 1) {
+        rc = run_chunk(0);
+    } else {
+        // one host thread per chunk: a launch costs the host about as much as these kernels run, so a
+        // single thread could not keep several streams busy
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        int rcs[MAX_CHUNKS];
+        char msgs[MAX_CHUNKS][256];
+        std::thread th[MAX_CHUNKS];
+        for (int i = 1; i < nch; ++i)
+            th[i] = std::thread([&, i]() {
+                (void)hipSetDevice(dev);
+                rcs[i] = run_chunk(i);
+                snprintf(msgs[i], sizeof(msgs[i]), "%s", mssr_last_error());
+            });
+        rcs[0] = run_chunk(0);
+        for (int i = 1; i < nch; ++i) th[i].join();
+        for (int i = nch - 1; i >= 0; --i)
+            if (rcs[i] != MSSR_OK) {
+                rc = rcs[i];
+                if (i > 0) set_error("%s", msgs[i]);
+            }
+    }
+    if (nch > 1) {            // join even after an error, so the caller's stream never runs ahead of a chunk
+        for (int i = 0; i < nch; ++i) {
+            (void)hipEventRecord(P->join[i], cs[i].s);
+            (void)hipStreamWaitEvent(stream, P->join[i], 0);
+        }
+    }
+    return rc;
+}
+
+}  // namespace mssr
+
+using namespace mssr;
+
+extern "C" int mssr_decode_step_fwd(const mssr_decode_plan* p, int step, void* stream) {
+    MSSR_REQUIRE(p, "decode_step_fwd: null plan");
+    return run_steps(p, step, step + 1, false, (hipStream_t)stream, "decode_step_fwd");
+}
+
+extern "C" int mssr_decode_step_bwd(const mssr_decode_plan* p, int step, void* stream) {
+    MSSR_REQUIRE(p, "decode_step_bwd: null plan");
+    return run_steps(p, step, step + 1, true, (hipStream_t)stream, "decode_step_bwd");
+}
+
 // All T steps forward (0 .. T-1) / backward (T-1 .. 0) in one call: the whole decode is one host
-// round trip, every kernel enqueued back to back on `stream`.
+// round trip, every kernel enqueued back to back, the batch chunks on concurrent streams that fork
+// from and join back into `stream`.
 extern "C" int mssr_decode_fwd(const mssr_decode_plan* p, void* stream) {
     MSSR_REQUIRE(p, "decode_fwd: null plan");
-    for (int s = 0; s < p->T; ++s)
-        if (int rc = mssr_decode_step_fwd(p, s, stream)) return rc;
-    return MSSR_OK;
+    return run_steps(p, 0, p->T, false, (hipStream_t)stream, "decode_fwd");
 }
 
 extern "C" int mssr_decode_bwd(const mssr_decode_plan* p, void* stream) {
     MSSR_REQUIRE(p, "decode_bwd: null plan");
-    for (int s = p->T - 1; s >= 0; --s)
-        if (int rc = mssr_decode_step_bwd(p, s, stream)) return rc;
-    return MSSR_OK;
+    return run_steps(p, 0, p->T, true, (hipStream_t)stream, "decode_bwd");
 }

@@ -187,17 +187,36 @@ using namespace mssr;
 
 extern "C" int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch) { return use_tile64(m, n, batch) ? 64 : 32; }
 
+static void fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
+    a.a = d->a; a.b = d->b; a.c = d->c; a.bias = d->bias; a.residual = d->residual; a.gate = d->gate;
+    a.m = d->m; a.n = d->n; a.k = d->k;
+    a.a_rs = d->a_rs; a.a_cs = d->a_cs; a.b_rs = d->b_rs; a.b_cs = d->b_cs;
+    a.ldc = d->ldc; a.ldr = d->ldr; a.ldg = d->ldg;
+    a.batch_inner = d->batch_inner;
+    a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
+    a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
+    a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    a.ksplit = 1;
+    a.partial = nullptr;
+    if (d->workspace && d->m <= 128 && d->k > 32 * 64) {
+        const int64_t need = gemm_skinny_ksplit(d->k) * d->m * d->n * (int64_t)sizeof(float);
+        if (d->workspace_bytes >= need && aligned(d->workspace, 16)) a.partial = (float*)d->workspace;
+    }
+    a.ln_colsum = d->ln_colsum; a.ln_mean = d->ln_mean; a.ln_rstd = d->ln_rstd; a.ln_eps = d->ln_eps;
+    const int ch = 16 / (int)dsize(d->in_dtype);
+    // 16-B vector loads need: base aligned, the non-unit stride and batch strides multiples of the chunk
+    const int64_t a_ld = d->a_cs == 1 ? d->a_rs : d->a_cs;
+    const int64_t b_ld = d->b_rs == 1 ? d->b_cs : d->b_rs;
+    a.a_vec = aligned(d->a, 16) && a_ld % ch == 0 && d->a_bo % ch == 0 && d->a_bi % ch == 0;
+    a.b_vec = aligned(d->b, 16) && b_ld % ch == 0 && d->b_bo % ch == 0 && d->b_bi % ch == 0;
+}
+
 // 1 when mssr_gemm routes this problem to the skinny-M kernel (same eligibility test, no launch)
 extern "C" int mssr_gemm_is_skinny(const mssr_gemm_desc* d) {
-    if (!d || d->no_skinny || d->in_dtype != MSSR_BF16 || d->batch_outer * d->batch_inner != 1) return 0;
-    if (d->m < 1 || d->m > 128 || d->k < 32 || d->k % 32 != 0 || d->beta != 0.f) return 0;
-    if (d->a_cs != 1 || d->b_rs != 1 || d->a_rs % 8 != 0 || d->b_cs % 8 != 0) return 0;
-    if (!aligned(d->a, 16) || !aligned(d->b, 16)) return 0;
-    if (d->k > 1024) {
-        const int64_t need = ((d->k / 32 + 31) / 32) * d->m * d->n * (int64_t)sizeof(float);
-        if (!d->workspace || d->workspace_bytes < need || !aligned(d->workspace, 16)) return 0;
-    }
-    return 1;
+    if (!d || d->no_skinny || !valid_dtype(d->in_dtype)) return 0;
+    GemmArgs a;
+    fill_args(d, a);
+    return gemm_skinny_eligible(a, d->in_dtype, d->batch_outer * d->batch_inner) ? 1 : 0;
 }
 
 extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
@@ -219,32 +238,23 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     MSSR_REQUIRE(!d->gate || d->ldg >= d->n, "gemm: ldg < n");
     MSSR_REQUIRE((d->m + 31) / 32 <= 65535, "gemm: m too large");
 
-    GemmArgs a;
-    a.a = d->a; a.b = d->b; a.c = d->c; a.bias = d->bias; a.residual = d->residual; a.gate = d->gate;
-    a.m = d->m; a.n = d->n; a.k = d->k;
-    a.a_rs = d->a_rs; a.a_cs = d->a_cs; a.b_rs = d->b_rs; a.b_cs = d->b_cs;
-    a.ldc = d->ldc; a.ldr = d->ldr; a.ldg = d->ldg;
-    a.batch_inner = d->batch_inner;
-    a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
-    a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
     MSSR_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of [0,1)", d->drop_p);
-    a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
-    a.ksplit = 1;
-    a.partial = nullptr;
-    if (d->workspace && d->m <= 128 && d->k > 1024) {
-        const int64_t need = ((d->k / 32 + 31) / 32) * d->m * d->n * (int64_t)sizeof(float);
-        if (d->workspace_bytes >= need && aligned(d->workspace, 16)) a.partial = (float*)d->workspace;
-    }
-    const int ch = 16 / (int)dsize(d->in_dtype);
-    // 16-B vector loads need: base aligned, the non-unit stride and batch strides multiples of the chunk
-    const int64_t a_ld = d->a_cs == 1 ? d->a_rs : d->a_cs;
-    const int64_t b_ld = d->b_rs == 1 ? d->b_cs : d->b_rs;
-    a.a_vec = aligned(d->a, 16) && a_ld % ch == 0 && d->a_bo % ch == 0 && d->a_bi % ch == 0;
-    a.b_vec = aligned(d->b, 16) && b_ld % ch == 0 && d->b_bo % ch == 0 && d->b_bi % ch == 0;
+    GemmArgs a;
+    fill_args(d, a);
     hipStream_t s = (hipStream_t)stream;
-    if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) { MSSR_LAUNCH_OK("gemm(skinny)"); }
+    const int pi = prof_begin(s);
+    if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+        prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_ksplit(d->k), batch, d->m, d->n, d->k);
+        MSSR_LAUNCH_OK("gemm(skinny)");
+    }
+    if (d->ln_colsum) {
+        set_error("gemm: the LayerNorm prologue needs the skinny kernel (bf16, m <= 128, k <= 2048, k %% 32 == 0, "
+                  "k-contiguous 16-byte aligned operands)");
+        return MSSR_ERR_UNSUPPORTED;
+    }
     if (d->in_dtype == MSSR_F32) launch<float, float>(a, batch, s);
     else if (d->out_dtype == MSSR_BF16) launch<bf16, bf16>(a, batch, s);
     else launch<bf16, float>(a, batch, s);
+    prof_end(pi, s, 0, d->in_dtype, d->out_dtype, use_tile64(d->m, d->n, batch) ? 64 : 32, batch, d->m, d->n, d->k);
     MSSR_LAUNCH_OK("gemm");
 }

@@ -22,6 +22,11 @@ struct GemmArgs {
     uint64_t drop_seed;
     float* partial;     // skinny split-K: fp32 slabs [ksplit][m][n]
     int ksplit;
+    // LayerNorm prologue (skinny kernel only): non-null ln_colsum switches it on
+    const float* ln_colsum;
+    float* ln_mean;
+    float* ln_rstd;
+    float ln_eps;
 };
 
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
@@ -44,5 +49,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float acc, int
 
 // returns true when the skinny path took the problem (gemm_skinny.hip)
 bool gemm_skinny_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
+bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch);
+int gemm_skinny_ksplit(int64_t k);
 
 }  // namespace mssr

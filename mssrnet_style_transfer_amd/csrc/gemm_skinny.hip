@@ -1,12 +1,21 @@
 // Skinny-M GEMM for the step-wise decode: C[M<=128, N] = A[M,K] . W[N,K]^T with both operands
-// k-contiguous (bf16).  Weight-streaming / latency-bound shape: M = 80 rows, N,K = 512..9632.
+// k-contiguous (bf16).  Latency-bound shape: M = 80 rows, N,K = 512..9632, 137+ of them chained per
+// decode step, so what counts is the length of ONE launch's dependency chain, not bandwidth.
 //
-// Mapping: one block per 16 output columns (x ksplit K-chunks); the block's 4 waves split the
-// K range between them, so every wave issues ALL the 16-B loads of its K sub-range for a group
-// of 4 k-steps straight into MFMA fragment registers (no LDS staging: A is L2-resident, W is
-// read exactly once), i.e. a K = 512 product exposes a single memory latency instead of 16
-// dependent tile iterations.  Partial accumulators of the 4 waves are summed through LDS; when
-// K is split across blocks the fp32 slabs go to a workspace and a second tiny kernel applies
+// Mapping (measured on MI355X, scratch microbenchmark: 3.9 us per chained 80x512x512 launch against
+// 7.4 us for a 16-column x all-rows block and 2.5 us for an empty kernel): one block per 16x16 output
+// tile, the block's 4 waves split K, every wave issues ALL its 16-B fragment loads (2 per k-step)
+// before the first MFMA, i.e. the kernel exposes a single memory round trip; a block moves 32 KB
+// through its CU's L1 instead of 96 KB, W is re-read by the M/16 row tiles out of L2 / Infinity Cache.
+// The four partial tiles are summed through LDS and the epilogue runs one element per thread with
+// its bias / residual / gate / C operands fetched at kernel start, under the main loads.
+//
+// LN mode (LayerNorm folded into the product: onmt/decoders/transformer.py:150-157 `LN -> Linear`):
+// A holds the raw rows x, W holds gamma-scaled weights, and
+//     LN(x) W^T + b = rstd (x W'^T - mean * colsum(W')) + (beta W^T + b)
+// with the row statistics taken from the fragments the block has loaded anyway.
+//
+// K > 2048 is split across blockIdx.z into fp32 slabs; a second tiny kernel reduces them and applies
 // the epilogue (deterministic, no atomics).
 #include "gemm_common.hpp"
 
@@ -15,14 +24,15 @@ namespace mssr {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SK_THREADS = 256;
 constexpr int SK_GROUP = 4;          // k-steps (of 32) in flight per wave
-constexpr int SK_MAX_STEPS = 32;     // k-steps per block without split-K (K <= 1024)
+constexpr int SK_MAX_STEPS = 64;     // k-steps per block without split-K (K <= 2048)
 
-template <int MF, typename TO>
+template <typename TO, bool LN>
 __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * MF * 256];
+    __shared__ __attribute__((aligned(16))) float red[4 * 256];
+    __shared__ float stat[4][16][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n0 = (int64_t)blockIdx.x * 16;
-    const int split = blockIdx.y;
+    const int64_t n0 = (int64_t)blockIdx.x * 16, m0 = (int64_t)blockIdx.y * 16;
+    const int split = blockIdx.z;
     const int64_t steps_total = p.k / 32;
     const int64_t per = (steps_total + p.ksplit - 1) / p.ksplit;
     const int64_t s_begin = split * per;
@@ -31,22 +41,27 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     const bf16* A = reinterpret_cast<const bf16*>(p.a);
     const bf16* W = reinterpret_cast<const bf16*>(p.b);
     const int koff = 8 * (lane >> 4);
-    int64_t arow[MF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) {
-        int64_t r = i * 16 + (lane & 15);
-        arow[i] = (r < p.m ? r : p.m - 1) * p.a_rs;
-    }
-    int64_t wn = n0 + (lane & 15);
+    const int64_t ar = m0 + (lane & 15), wn = n0 + (lane & 15);
+    const int64_t arow = (ar < p.m ? ar : p.m - 1) * p.a_rs;
     const int64_t wrow = (wn < p.n ? wn : p.n - 1) * p.b_cs;     // B viewed [k,n]: n stride = b_cs
 
-    f32x4 acc[MF];
-#pragma unroll
-    for (int i = 0; i < MF; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // the element this thread finishes, and its epilogue operands (issued before the main loads)
+    const int64_t erow = m0 + (threadIdx.x >> 4), ecol = n0 + (threadIdx.x & 15);
+    const bool eok = erow < p.m && ecol < p.n;
+    float bias = 0.f, res = 0.f, gate = 1.f, cold = 0.f, lns = 0.f;
+    if (eok && p.ksplit == 1) {
+        if (p.bias) bias = p.bias[ecol];
+        if (p.residual) res = to_f(reinterpret_cast<const bf16*>(p.residual)[erow * p.ldr + ecol]);
+        if (p.gate) gate = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol]);
+        if (p.beta != 0.f) cold = to_f(reinterpret_cast<const TO*>(p.c)[erow * p.ldc + ecol]);
+        if (LN) lns = p.ln_colsum[ecol];
+    }
 
-    // wave w owns k-steps s_begin + w, + 4, + 8 ... ; processed SK_GROUP at a time
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx = 0.f, sxx = 0.f;
+    // wave w owns k-steps s_begin + w, + 4, + 8 ... ; SK_GROUP of them in flight at a time
     for (int64_t s0 = s_begin + wave; s0 < s_end; s0 += 4 * SK_GROUP) {
-        bf16x8 fa[SK_GROUP][MF], fb[SK_GROUP];
+        bf16x8 fa[SK_GROUP], fb[SK_GROUP];
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
             // unconditional loads (clamped to the last valid k-step): a branch around a load makes
@@ -55,49 +70,70 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             s = s < s_end ? s : s_end - 1;
             const int64_t k = s * 32 + koff;
             fb[g] = *reinterpret_cast<const bf16x8*>(W + wrow + k);
-#pragma unroll
-            for (int i = 0; i < MF; ++i) fa[g][i] = *reinterpret_cast<const bf16x8*>(A + arow[i] + k);
+            fa[g] = *reinterpret_cast<const bf16x8*>(A + arow + k);
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the whole batch of loads ahead of the first MFMA
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
             // k-steps past the end were loaded from a clamped address: zero the weight fragment with a
             // bit mask (no branch, so the loads above stay one batch in flight)
-            const unsigned msk = (s0 + 4 * g < s_end) ? 0xffffffffu : 0u;
+            const bool live = s0 + 4 * g < s_end;
+            const unsigned msk = live ? 0xffffffffu : 0u;
             u32x4 wb = __builtin_bit_cast(u32x4, fb[g]);
             wb &= msk;
-            const bf16x8 fbm = __builtin_bit_cast(bf16x8, wb);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g], __builtin_bit_cast(bf16x8, wb), acc, 0, 0, 0);
+            if (LN && live) {
 #pragma unroll
-            for (int i = 0; i < MF; ++i)
-                acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g][i], fbm, acc[i], 0, 0, 0);
+                for (int j = 0; j < 8; ++j) {
+                    const float x = (float)fa[g][j];
+                    sx += x;
+                    sxx += x * x;
+                }
+            }
         }
     }
-    // cross-wave reduction through LDS: red[wave][frag][lane*4 + r]
+    // partial tiles -> LDS as [wave][row*16 + col]  (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
 #pragma unroll
-    for (int i = 0; i < MF; ++i)
-        *reinterpret_cast<f32x4*>(&red[(wave * MF + i) * 256 + lane * 4]) = acc[i];
+    for (int r = 0; r < 4; ++r) red[wave * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+    if (LN) {       // row sums: the 4 lanes (lane & 15, lane >> 4 = 0..3) of a wave hold one row's k-chunks
+        sx += __shfl_xor(sx, 16, 64);
+        sx += __shfl_xor(sx, 32, 64);
+        sxx += __shfl_xor(sxx, 16, 64);
+        sxx += __shfl_xor(sxx, 32, 64);
+        if (lane < 16) {
+            stat[wave][lane][0] = sx;
+            stat[wave][lane][1] = sxx;
+        }
+    }
     __syncthreads();
-    TO* C = reinterpret_cast<TO*>(p.c);
-    const bf16* R = reinterpret_cast<const bf16*>(p.residual);
-    const bf16* G = reinterpret_cast<const bf16*>(p.gate);
-    const int64_t col = n0 + (lane & 15);
-    const float bias = (p.bias && col < p.n) ? p.bias[col] : 0.f;
-    for (int i = wave; i < MF; i += 4) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&red[(0 * MF + i) * 256 + lane * 4]);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            const f32x4 t = *reinterpret_cast<const f32x4*>(&red[(w * MF + i) * 256 + lane * 4]);
-            v += t;
-        }
-        if (col >= p.n) continue;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = i * 16 + (lane >> 4) * 4 + r;
-            if (row >= p.m) continue;
-            if (p.ksplit > 1) p.partial[((int64_t)split * p.m + row) * p.n + col] = v[r];
-            else epilogue_store<bf16, TO>(p, v[r], row, col, bias, C, R, G, 0);
+    if (!eok) return;
+    const int t = threadIdx.x;
+    float v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
+    if (p.ksplit > 1) {
+        p.partial[((int64_t)split * p.m + erow) * p.n + ecol] = v;
+        return;
+    }
+    if (LN) {
+        const int rl = t >> 4;
+        const float s1 = (stat[0][rl][0] + stat[1][rl][0]) + (stat[2][rl][0] + stat[3][rl][0]);
+        const float s2 = (stat[0][rl][1] + stat[1][rl][1]) + (stat[2][rl][1] + stat[3][rl][1]);
+        const float mean = s1 / (float)p.k;
+        const float var = fmaxf(s2 / (float)p.k - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + p.ln_eps);
+        v = rstd * (v - mean * lns);
+        if (blockIdx.x == 0 && (t & 15) == 0) {
+            if (p.ln_mean) p.ln_mean[erow] = mean;
+            if (p.ln_rstd) p.ln_rstd[erow] = rstd;
         }
     }
+    v = p.alpha * v + bias;
+    if (p.relu) v = fmaxf(v, 0.f);
+    if (p.drop_p > 0.f)
+        v = drop_keep(p.drop_seed, (uint64_t)(erow * p.n + ecol), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+    v += res;
+    if (p.gate) v = gate > 0.f ? v : 0.f;
+    if (p.beta != 0.f) v += p.beta * cold;
+    reinterpret_cast<TO*>(p.c)[erow * p.ldc + ecol] = from_f<TO>(v);
 }
 
 template <typename TO>
@@ -115,19 +151,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const GemmArgs 
 }
 
 template <typename TO>
-static void skinny_launch(GemmArgs a, hipStream_t s) {
-    const int mf = (int)((a.m + 15) / 16);
-    const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)a.ksplit);
-    switch (mf) {
-        case 1: gemm_skinny_kernel<1, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        case 2: gemm_skinny_kernel<2, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        case 3: gemm_skinny_kernel<3, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        case 4: gemm_skinny_kernel<4, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        case 5: gemm_skinny_kernel<5, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        case 6: gemm_skinny_kernel<6, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        case 7: gemm_skinny_kernel<7, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-        default: gemm_skinny_kernel<8, TO><<<grid, SK_THREADS, 0, s>>>(a); break;
-    }
+static void skinny_launch(const GemmArgs& a, hipStream_t s) {
+    const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
+    if (a.ln_colsum) gemm_skinny_kernel<TO, true><<<grid, SK_THREADS, 0, s>>>(a);
+    else gemm_skinny_kernel<TO, false><<<grid, SK_THREADS, 0, s>>>(a);
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;
         if (blocks > 1024) blocks = 1024;
@@ -135,17 +162,22 @@ static void skinny_launch(GemmArgs a, hipStream_t s) {
     }
 }
 
-bool gemm_skinny_try(const GemmArgs& a0, int in_dtype, int out_dtype, int64_t batch, hipStream_t s) {
+int gemm_skinny_ksplit(int64_t k) { return (int)((k / 32 + SK_MAX_STEPS - 1) / SK_MAX_STEPS); }
+
+bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch) {
     if (in_dtype != MSSR_BF16 || batch != 1) return false;
-    if (a0.m < 1 || a0.m > 128 || a0.k < 32 || a0.k % 32 != 0 || a0.beta != 0.f) return false;
-    if (a0.a_cs != 1 || a0.b_rs != 1) return false;                       // both operands k-contiguous
-    if (a0.a_rs % 8 != 0 || a0.b_cs % 8 != 0 || !aligned(a0.a, 16) || !aligned(a0.b, 16)) return false;
+    if (a.m < 1 || a.m > 128 || a.k < 32 || a.k % 32 != 0) return false;
+    if (a.a_cs != 1 || a.b_rs != 1) return false;                       // both operands k-contiguous
+    if (a.a_rs % 8 != 0 || a.b_cs % 8 != 0 || !aligned(a.a, 16) || !aligned(a.b, 16)) return false;
+    const int ks = gemm_skinny_ksplit(a.k);
+    if (ks > 1 && (!a.partial || a.ln_colsum)) return false;             // no workspace / LN needs whole rows
+    return true;
+}
+
+bool gemm_skinny_try(const GemmArgs& a0, int in_dtype, int out_dtype, int64_t batch, hipStream_t s) {
+    if (!gemm_skinny_eligible(a0, in_dtype, batch)) return false;
     GemmArgs a = a0;
-    const int64_t steps = a.k / 32;
-    a.ksplit = (int)((steps + SK_MAX_STEPS - 1) / SK_MAX_STEPS);
-    if (a.ksplit > 1) {
-        if (!a.partial) return false;      // caller gave no workspace: use the general kernel
-    }
+    a.ksplit = gemm_skinny_ksplit(a.k);
     if (out_dtype == MSSR_BF16) skinny_launch<bf16>(a, s);
     else skinny_launch<float>(a, s);
     return true;

@@ -15,6 +15,7 @@ a parameter's version changes (i.e. after an optimizer step).
 """
 import ctypes
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -169,6 +170,7 @@ class _SoftDecode(Function):
         plan.B, plan.d, plan.heads, plan.ff, plan.n_layers = B, d, spec.heads, ff, NL
         plan.V, plan.Vp, plan.Ls, plan.T = V, Vp, Ls, T
         plan.save, plan.training = int(spec.save), int(spec.training)
+        plan.n_chunks = max(1, min(8, int(os.environ.get("MSSR_DECODE_CHUNKS", "1")), B))
         plan.p_drop, plan.p_attn, plan.temperature, plan.seed = spec.p_drop, spec.p_attn, spec.temperature, spec.seed
         plan.layers = pk.layers
         for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b"):

@@ -95,8 +95,10 @@ def _workspace(device):
 
 
 def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, alpha=1.0, out=None, beta=0.0,
-         drop_p=0.0, drop_seed=0, no_skinny=False):
-    """out[..., M, N] = epilogue(alpha * a[..., M, K] @ (b[..., N, K]^T if tb else b[..., K, N]))."""
+         drop_p=0.0, drop_seed=0, no_skinny=False, ln=None):
+    """out[..., M, N] = epilogue(alpha * a[..., M, K] @ (b[..., N, K]^T if tb else b[..., K, N])).
+    ln = (colsum [N], mean_out [M] or None, rstd_out [M] or None, eps): LayerNorm prologue of the
+    skinny kernel (see mssr_gemm_desc.ln_colsum)."""
     L.require_cuda(a, b)
     a, a_rs, a_cs = _mat(a)
     b, s0, s1 = _mat(b)
@@ -133,43 +135,41 @@ def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, a
     d.alpha, d.beta, d.relu = alpha, beta, int(relu)
     d.in_dtype, d.out_dtype = L.dt(a), L.dt(out)
     d.drop_p, d.drop_seed, d.no_skinny = drop_p, drop_seed, int(no_skinny)
-    if m <= 128 and k > 1024:
+    if m <= 128 and k > 2048:
         ws = _workspace(a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-    prof = _state.get("profile")
-    if prof is None:
-        L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
-        return out
-    # bench.py instrumentation: HIP events around this launch, on the stream it is enqueued on
-    lib = L.load()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    L.check(lib.mssr_gemm(d, L.stream()), "gemm")
-    e1.record()
-    isz, osz = a.element_size(), out.element_size()
-    nb = bo * bi
-    kname = ("gemm_skinny_kernel<%d,%s>" % ((m + 15) // 16, "bf16" if osz == 2 else "f32")
-             if lib.mssr_gemm_is_skinny(d) else
-             "gemm_kernel<%s,%s,%d>" % ("bf16" if isz == 2 else "f32", "bf16" if osz == 2 else "f32",
-                                        lib.mssr_gemm_tile(m, n, nb)))
-    prof.append(dict(kernel=kname,
-                     shape=(nb, m, n, k), bytes=nb * ((m * k + k * n) * isz + m * n * osz), flops=2 * nb * m * n * k,
-                     events=(e0, e1)))
+    if ln is not None:
+        d.ln_colsum, d.ln_mean, d.ln_rstd, d.ln_eps = ln[0].data_ptr(), L.ptr(ln[1]), L.ptr(ln[2]), float(ln[3])
+    L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
     return out
 
 
-def start_profile():
-    """Record (kernel, shape, algorithmic bytes/flops, HIP events) for every GEMM launch."""
-    _state["profile"] = []
+def start_profile(max_records=200000):
+    """Time every GEMM launch (from Python or from inside the decode engine) with HIP events on its
+    stream (mssr_prof_start, include/mssr_hip.h)."""
+    L.check(L.load().mssr_prof_start(int(max_records)), "prof_start")
 
 
 def stop_profile():
-    rec, _state["profile"] = _state.get("profile") or [], None
-    torch.cuda.synchronize()
-    for r in rec:
-        e0, e1 = r.pop("events")
-        r["ms"] = e0.elapsed_time(e1)
-    return rec
+    """-> list of dicts (kernel, shape, algorithmic bytes / flops, ms) of the launches since start_profile."""
+    import ctypes
+    lib = L.load()
+    n = lib.mssr_prof_stop()
+    if n < 0:
+        L.check(1, "prof_stop")
+    out, r = [], L.ProfRecord()
+    for i in range(n):
+        L.check(lib.mssr_prof_get(i, ctypes.byref(r)), "prof_get")
+        isz, osz = (2 if r.in_dtype == L.BF16 else 4), (2 if r.out_dtype == L.BF16 else 4)
+        tin, tout = ("bf16" if isz == 2 else "f32"), ("bf16" if osz == 2 else "f32")
+        if r.kernel == 1:
+            name = "gemm_skinny_kernel<%d,%s>%s" % ((r.m + 15) // 16, tout, "+splitK" if r.tile > 1 else "")
+        else:
+            name = "gemm_kernel<%s,%s,%d>" % (tin, tout, r.tile)
+        out.append(dict(kernel=name, in_dtype=tin, shape=(r.batch, r.m, r.n, r.k), ms=r.ms,
+                        bytes=r.batch * ((r.m * r.k + r.k * r.n) * isz + r.m * r.n * osz),
+                        flops=2 * r.batch * r.m * r.n * r.k))
+    return out
 
 
 class _Matmul(Function):

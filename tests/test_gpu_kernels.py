@@ -442,3 +442,38 @@ def test_gemm_skinny_path(ops, M, N, K):
     assert abs(frac - 0.75) < 0.05 or M * N < 2000
     sel = kept != 0
     assert_close(kept[sel], (out32 / 0.75)[sel], 1e-5, "dropout scaling")
+
+
+def test_gemm_skinny_beta_accumulates(ops):
+    """beta * C_old in the skinny epilogue (the decode backward's dprobs feedback, fp32 output)."""
+    torch.manual_seed(5)
+    a = torch.randn(80, 512).bfloat16().cuda()
+    w = torch.randn(1000, 512).bfloat16().cuda()
+    c0 = torch.randn(80, 1000).cuda()
+    out = c0.clone()
+    ops.gemm(a, w, True, torch.float32, out=out, beta=1.0)
+    assert_close(out, c0.double() + a.double() @ w.double().t(), 2e-5 * math.sqrt(512), "beta")
+
+
+@pytest.mark.parametrize("M,N,K", [(80, 1536, 512), (20, 512, 512), (80, 1024, 512), (33, 48, 256)])
+def test_gemm_skinny_layernorm_prologue(ops, M, N, K):
+    """LayerNorm folded into the product: raw rows x, gamma-scaled weights, column sums and a folded
+    bias give LN(x) W^T + b and the row statistics, against fp64 LayerNorm -> Linear."""
+    torch.manual_seed(M * N + K)
+    x = (torch.randn(M, K) * 1.7 + 0.3).bfloat16()
+    gamma, beta = torch.rand(K) + 0.5, torch.randn(K) * 0.2
+    W, b = torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    xd = x.double()
+    mean = xd.mean(1, keepdim=True)
+    var = xd.var(1, unbiased=False, keepdim=True)
+    ref = ((xd - mean) / (var + 1e-6).sqrt() * gamma.double() + beta.double()) @ W.double().t() + b.double()
+    wg = (W * gamma).bfloat16()
+    colsum = wg.float().sum(1).cuda()
+    bias = (W.double() @ beta.double() + b.double()).float().cuda()
+    mo, ro = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    out = ops.gemm(x.cuda(), wg.cuda(), True, torch.bfloat16, bias=bias, ln=(colsum, mo, ro, 1e-6))
+    assert_close(out.float(), ref, 2e-2, "ln-gemm")
+    assert_close(mo, mean.squeeze(1), 1e-4, "mean", floor=1e-5)
+    assert_close(ro, 1.0 / (var.squeeze(1) + 1e-6).sqrt(), 1e-4, "rstd")
+    with pytest.raises(RuntimeError):
+        ops.gemm(x.cuda(), wg.cuda(), True, torch.bfloat16, bias=bias, ln=(colsum, mo, ro, 1e-6), no_skinny=True)
