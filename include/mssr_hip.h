@@ -201,6 +201,12 @@ typedef struct {
     const float *ln1_g, *ln1_b;   /* layer_norm_1 */
     const float *ln2_g, *ln2_b;   /* layer_norm_2 */
     const float *lnf_g, *lnf_b;   /* feed_forward.layer_norm */
+    /* LayerNorm folded into the Linear that follows it (mssr_decode_plan.fuse_ln; see mssr_gemm_desc.ln_colsum):
+     * wg_* = gamma-scaled weights (compute dtype), cs_* = their row sums, bf_* = W beta + b (float).
+     * qkv <- layer_norm_1, cq <- layer_norm_2, w_1 <- feed_forward.layer_norm.  May be NULL when fuse_ln = 0. */
+    const void *wg_qkv, *wg_cq, *wg_1;
+    const float *cs_qkv, *cs_cq, *cs_1;
+    const float *bf_qkv, *bf_cq, *bf_1;
 } mssr_dec_layer;
 
 typedef struct {
@@ -213,6 +219,9 @@ typedef struct {
     int n_chunks;                 /* 1..8: the batch is cut into this many row chunks whose (independent)
                                    * dependency chains run on concurrent internal streams forked from / joined
                                    * into the caller's stream; dropout masks depend on the chunking */
+    int fuse_ln;                  /* 1 (bf16 only): the four LayerNorms before a Linear run inside that Linear's
+                                   * kernel; the n1/n2/n3 kinds of actD and nf are then NOT written (the caller
+                                   * recomputes them from X / h1 / h2 and `stats` for the weight gradients) */
     float p_drop, p_attn, temperature;
     uint64_t seed;
     const mssr_dec_layer* layers; /* host array [n_layers] */
@@ -223,6 +232,8 @@ typedef struct {
     const void* wt_gen;           /* its transpose [d, Vp], padded columns zero (backward) */
     const float* b_gen;
     const float *lnF_g, *lnF_b;   /* decoder.layer_norm */
+    const void* wg_gen;           /* fuse_ln: generator weights scaled by lnF_g [V, d], row sums, W lnF_b + b */
+    const float *cs_gen, *bf_gen;
     const void* mem_kv;           /* [B, Ls, n_layers, 2d]: context keys|values of the memory bank, all layers */
     const uint8_t* src_mask;      /* [B, Ls], nonzero = source padding */
     void* in_all;                 /* [T+1][B, Vp] step inputs; slot 0 = one-hot <s>; padded columns zero */

@@ -37,17 +37,18 @@ class DecLayer(Structure):
     _fields_ = [(n, c_void_p) for n in (
         "w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2", "wt_2",
         "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2",
-        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "lnf_g", "lnf_b")]
+        "ln1_g", "ln1_b", "ln2_g", "ln2_b", "lnf_g", "lnf_b",
+        "wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1")]
 
 
 class DecodePlan(Structure):
     """mssr_decode_plan (include/mssr_hip.h)."""
     _fields_ = ([(n, c_int) for n in ("dtype", "B", "d", "heads", "ff", "n_layers", "V", "Vp", "Ls", "T", "save",
-                                      "training", "n_chunks")]
+                                      "training", "n_chunks", "fuse_ln")]
                 + [("p_drop", c_float), ("p_attn", c_float), ("temperature", c_float), ("seed", c_uint64),
                    ("layers", POINTER(DecLayer))]
                 + [(n, c_void_p) for n in ("emb_t", "emb", "pe", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b",
-                                           "mem_kv", "src_mask", "in_all", "probs", "X", "qkv", "actD", "actF",
+                                           "wg_gen", "cs_gen", "bf_gen", "mem_kv", "src_mask", "in_all", "probs", "X", "qkv", "actD", "actF",
                                            "stats", "nf", "logits", "tmp", "gemm_ws")]
                 + [("gemm_ws_bytes", c_int64)]
                 + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dkv_acc",

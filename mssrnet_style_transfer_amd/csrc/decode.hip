@@ -184,13 +184,16 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
 }
 
 // dx = dres + rstd * (a - mean(a) - xhat * mean(a * xhat)), a = gamma * dy   (no parameter gradients:
-// those are contracted once over all steps by the caller)
+// those are contracted once over all steps by the caller).  dx2 = keep(seed, i) * dx * extra / (1 - p):
+// the same gradient pushed back through the dropout of the block below (the mask is regenerated from
+// the seed the forward used), i.e. the gradient of that block's last Linear output.
 template <typename T>
 __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const T* __restrict__ dres,
-                                                        T* __restrict__ dx, int rows, int d) {
+                                                        T* __restrict__ dx, T* __restrict__ dx2, int rows, int d,
+                                                        float p, uint64_t seed, float extra) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -211,15 +214,24 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
         }
     }
     const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
+    const float sc = extra / (1.0f - p);
+    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
     for (int c = lane * 4; c < d; c += 256) {
-        float xv[4], dv[4], g[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4];
+        float xv[4], dv[4], g[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4], o2[4];
         V4<T>::load(xr + c, xv);
         V4<T>::load(dr + c, dv);
         V4<float>::load(gamma + c, g);
         if (dres) V4<T>::load(dres + (int64_t)row * d + c, rr);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = rr[j] + rs * (dv[j] * g[j] - c1 - (xv[j] - mu) * rs * c2);
+        for (int j = 0; j < 4; ++j) {
+            o[j] = rr[j] + rs * (dv[j] * g[j] - c1 - (xv[j] - mu) * rs * c2);
+            // the forward rounded nothing between dropout and the residual add, but dx IS stored in T:
+            // replay from the stored value so that dx2 matches a separate pass over dx bit for bit
+            const float ov = to_f(from_f<T>(o[j]));
+            o2[j] = (p > 0.f) ? (hash_u32(seed, (uint64_t)row * d + c + j) >= thr ? ov * sc : 0.f) : ov * extra;
+        }
         V4<T>::store(dx + (int64_t)row * d + c, o);
+        if (dx2) V4<T>::store(dx2 + (int64_t)row * d + c, o2);
     }
 }
 
@@ -320,7 +332,8 @@ static inline char* at(void* base, int64_t elems, size_t es) { return (char*)bas
 // C[m, n] = A[m,k] . W[n,k]^T (+ epilogue) -- every decode GEMM has this NT, k-contiguous form
 static int gemm_nt(const Ctx& c, const void* a, int64_t lda, const void* w, int64_t ldw, void* out, int64_t ldc,
                    int64_t m, int64_t n, int64_t k, const float* bias, int relu, const void* residual, int64_t ldr,
-                   const void* gate, int64_t ldg, float alpha, float beta, int out_dt, float drop_p, uint64_t seed) {
+                   const void* gate, int64_t ldg, float alpha, float beta, int out_dt, float drop_p, uint64_t seed,
+                   const float* ln_colsum = nullptr, float* ln_mean = nullptr, float* ln_rstd = nullptr) {
     mssr_gemm_desc d;
     d.a = a; d.b = w; d.c = out; d.bias = bias; d.residual = residual; d.gate = gate;
     d.m = m; d.n = n; d.k = k;
@@ -332,7 +345,7 @@ static int gemm_nt(const Ctx& c, const void* a, int64_t lda, const void* w, int6
     d.in_dtype = c.dt; d.out_dtype = out_dt;
     d.drop_p = drop_p; d.drop_seed = seed;
     d.workspace = c.ws; d.workspace_bytes = c.ws_bytes; d.no_skinny = 0;
-    d.ln_colsum = nullptr; d.ln_mean = nullptr; d.ln_rstd = nullptr; d.ln_eps = 0.f;
+    d.ln_colsum = ln_colsum; d.ln_mean = ln_mean; d.ln_rstd = ln_rstd; d.ln_eps = 1e-6f;
     return mssr_gemm(&d, c.s);
 }
 
@@ -390,6 +403,16 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
                      p->nf && p->logits && p->tmp,
                  "%s: null buffer in plan", who);
     MSSR_REQUIRE(p->temperature > 0.f, "%s: temperature must be positive", who);
+    if (p->fuse_ln) {
+        MSSR_REQUIRE(p->dtype == MSSR_BF16 && p->d % 32 == 0 && p->d <= 2048,
+                     "%s: fuse_ln needs bf16 and a model dim that is a multiple of 32, <= 2048", who);
+        MSSR_REQUIRE(p->wg_gen && p->cs_gen && p->bf_gen, "%s: fuse_ln needs the folded generator weights", who);
+        for (int l = 0; l < p->n_layers; ++l) {
+            const mssr_dec_layer& L = p->layers[l];
+            MSSR_REQUIRE(L.wg_qkv && L.wg_cq && L.wg_1 && L.cs_qkv && L.cs_cq && L.cs_1 && L.bf_qkv && L.bf_cq && L.bf_1,
+                         "%s: fuse_ln needs the folded weights of layer %d", who, l);
+        }
+    }
     MSSR_REQUIRE(p->n_chunks >= 1 && p->n_chunks <= MAX_CHUNKS, "%s: n_chunks must be in [1, %d]", who, MAX_CHUNKS);
     MSSR_REQUIRE(p->p_drop >= 0.f && p->p_drop < 1.f && p->p_attn >= 0.f && p->p_attn < 1.f, "%s: bad dropout", who);
     return MSSR_OK;
@@ -442,6 +465,7 @@ static int step_fwd(const Ctx& c, int step) {
     const size_t es = c.es;
     const int64_t Rd = (int64_t)R * d;
     const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
+    const bool fuse = p->fuse_ln != 0;
     int rc;
     // embedding of the (soft) input: e = in[step] . E ; x0 = dropout(e*sqrt(d) + pe[step])
     const void* in = G.rows(p->in_all, step, p->Vp);
@@ -466,24 +490,36 @@ static int step_fwd(const Ctx& c, int step) {
         char* qkv_0 = G.qkv(l, 0);               // this chunk's rows of step 0: the cache base
         char* qkv_s = G.qkv(l, step);
         // --- self attention block
-        if ((rc = mssr_layernorm_fwd(x, L.ln1_g, L.ln1_b, n1, G.stat(l * 3 + 0, 0), G.stat(l * 3 + 0, 1), R, d, 1e-6f,
-                                     c.dt, c.s)))
-            return rc;
-        if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, 3 * d, R, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f, 0.f,
-                          c.dt, 0.f, 0)))
-            return rc;
+        if (fuse) {     // LayerNorm folded into the projection (stats written by the GEMM, n1 not materialised)
+            if ((rc = gemm_nt(c, x, d, L.wg_qkv, d, qkv_s, 3 * d, R, 3 * d, d, L.bf_qkv, 0, nullptr, 0, nullptr, 0, 1.f,
+                              0.f, c.dt, 0.f, 0, L.cs_qkv, G.stat(l * 3 + 0, 0), G.stat(l * 3 + 0, 1))))
+                return rc;
+        } else {
+            if ((rc = mssr_layernorm_fwd(x, L.ln1_g, L.ln1_b, n1, G.stat(l * 3 + 0, 0), G.stat(l * 3 + 0, 1), R, d,
+                                         1e-6f, c.dt, c.s)))
+                return rc;
+            if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, 3 * d, R, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f,
+                              0.f, c.dt, 0.f, 0)))
+                return rc;
+        }
         DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
                 (int64_t)B * 3 * d, nullptr, 0, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, R, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
                           site_seed(c, step, l, 2))))
             return rc;
         // --- context attention block (keys / values of the memory bank were projected once)
-        if ((rc = mssr_layernorm_fwd(h1, L.ln2_g, L.ln2_b, n2, G.stat(l * 3 + 1, 0), G.stat(l * 3 + 1, 1), R, d, 1e-6f,
-                                     c.dt, c.s)))
-            return rc;
-        if ((rc = gemm_nt(c, n2, d, L.w_cq, d, qc, d, R, d, d, L.b_cq, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, 0.f,
-                          0)))
-            return rc;
+        if (fuse) {
+            if ((rc = gemm_nt(c, h1, d, L.wg_cq, d, qc, d, R, d, d, L.bf_cq, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                              0.f, 0, L.cs_cq, G.stat(l * 3 + 1, 0), G.stat(l * 3 + 1, 1))))
+                return rc;
+        } else {
+            if ((rc = mssr_layernorm_fwd(h1, L.ln2_g, L.ln2_b, n2, G.stat(l * 3 + 1, 0), G.stat(l * 3 + 1, 1), R, d,
+                                         1e-6f, c.dt, c.s)))
+                return rc;
+            if ((rc = gemm_nt(c, n2, d, L.w_cq, d, qc, d, R, d, d, L.b_cq, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                              0.f, 0)))
+                return rc;
+        }
         const char* mkv = G.mem_kv(l);                                      // [B, Ls, NL, 2d], layer l
         DT_CALL(c, launch_attn_fwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
                 (int64_t)NL * 2 * d, G.src_mask(), p->Ls, ctx2, d, p->Ls, pa, site_seed(c, step, l, 3));
@@ -491,24 +527,36 @@ static int step_fwd(const Ctx& c, int step) {
                           site_seed(c, step, l, 4))))
             return rc;
         // --- feed forward block
-        if ((rc = mssr_layernorm_fwd(h2, L.lnf_g, L.lnf_b, n3, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1), R, d, 1e-6f,
-                                     c.dt, c.s)))
-            return rc;
-        if ((rc = gemm_nt(c, n3, d, L.w_1, d, inter, ff, R, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          site_seed(c, step, l, 5))))
-            return rc;
+        if (fuse) {
+            if ((rc = gemm_nt(c, h2, d, L.wg_1, d, inter, ff, R, ff, d, L.bf_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                              pd, site_seed(c, step, l, 5), L.cs_1, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1))))
+                return rc;
+        } else {
+            if ((rc = mssr_layernorm_fwd(h2, L.lnf_g, L.lnf_b, n3, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1), R, d,
+                                         1e-6f, c.dt, c.s)))
+                return rc;
+            if ((rc = gemm_nt(c, n3, d, L.w_1, d, inter, ff, R, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+                              pd, site_seed(c, step, l, 5))))
+                return rc;
+        }
         if ((rc = gemm_nt(c, inter, ff, L.w_2, ff, G.X(l + 1), d, R, d, ff, L.b_2, 0, h2, d, nullptr, 0, 1.f, 0.f, c.dt,
                           pd, site_seed(c, step, l, 6))))
             return rc;
     }
     // final LayerNorm, generator Linear, softmax(/T)
     char* nf = G.rows(p->nf, G.slot, d);
-    if ((rc = mssr_layernorm_fwd(G.X(NL), p->lnF_g, p->lnF_b, nf, G.stat(NL * 3, 0), G.stat(NL * 3, 1), R, d, 1e-6f,
-                                 c.dt, c.s)))
-        return rc;
-    if ((rc = gemm_nt(c, nf, d, p->w_gen, d, G.logits(), p->Vp, R, p->V, d, p->b_gen, 0, nullptr, 0, nullptr, 0, 1.f,
-                      0.f, c.dt, 0.f, 0)))
-        return rc;
+    if (fuse) {
+        if ((rc = gemm_nt(c, G.X(NL), d, p->wg_gen, d, G.logits(), p->Vp, R, p->V, d, p->bf_gen, 0, nullptr, 0, nullptr,
+                          0, 1.f, 0.f, c.dt, 0.f, 0, p->cs_gen, G.stat(NL * 3, 0), G.stat(NL * 3, 1))))
+            return rc;
+    } else {
+        if ((rc = mssr_layernorm_fwd(G.X(NL), p->lnF_g, p->lnF_b, nf, G.stat(NL * 3, 0), G.stat(NL * 3, 1), R, d, 1e-6f,
+                                     c.dt, c.s)))
+            return rc;
+        if ((rc = gemm_nt(c, nf, d, p->w_gen, d, G.logits(), p->Vp, R, p->V, d, p->b_gen, 0, nullptr, 0, nullptr, 0, 1.f,
+                          0.f, c.dt, 0.f, 0)))
+            return rc;
+    }
     float* probs = p->probs + ((int64_t)step * B + G.r0) * p->V;
     void* copy = G.rows(p->in_all, step + 1, p->Vp);                        // in_all has T+1 slots
     const int ne = (p->V + 255) / 256;
@@ -529,24 +577,23 @@ static int step_bwd(const Ctx& c, int step) {
     const Geo G(c, step);
     const int B = G.B, R = G.R, d = G.d, ff = G.ff, NL = G.NL;
     const size_t es = c.es;
-    const int64_t Rd = (int64_t)R * d;
     const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
     const float keep = pd > 0.f ? 1.0f / (1.0f - pd) : 1.0f;
     int rc;
     // gradient slabs: dactD [n_layers][7][T][B,d] = dn1 | d_so | dn2 | d_cq | d_co | dn3 | d_f2 (gradients of the
     // outputs of LN1, self out-proj, LN2, ctx query proj, ctx out-proj, LN3, W2); dactF [n_layers][T][B,ff] = d_f1
-    auto drop_replay = [&](const void* x, void* y, int64_t n, uint64_t seed, float extra) {
-        const unsigned g = (unsigned)((n / 4 + 255) / 256);
-        if (c.dt == MSSR_F32) drop_replay_kernel<float><<<g, 256, 0, c.s>>>((const float*)x, (float*)y, n, pd, seed, extra);
-        else drop_replay_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)x, (bf16*)y, n, pd, seed, extra);
-    };
-    auto ln_bwd = [&](const void* dy, const void* x, const float* g, int idx, const void* dres, void* dx) {
+    // LayerNorm backward into the running residual gradient dx, plus dx2 = that gradient pushed through the
+    // dropout (site seed) of the block below: the gradient of the block's last Linear output
+    auto ln_bwd = [&](const void* dy, const void* x, const float* g, int idx, const void* dres, void* dx, void* dx2,
+                      uint64_t seed, float extra) {
         if (c.dt == MSSR_F32)
             ln_bwd_dx_kernel<float><<<(R + 3) / 4, 256, 0, c.s>>>((const float*)dy, (const float*)x, g, G.stat(idx, 0),
-                                                                 G.stat(idx, 1), (const float*)dres, (float*)dx, R, d);
+                                                                 G.stat(idx, 1), (const float*)dres, (float*)dx,
+                                                                 (float*)dx2, R, d, pd, seed, extra);
         else
             ln_bwd_dx_kernel<bf16><<<(R + 3) / 4, 256, 0, c.s>>>((const bf16*)dy, (const bf16*)x, g, G.stat(idx, 0),
-                                                                G.stat(idx, 1), (const bf16*)dres, (bf16*)dx, R, d);
+                                                                G.stat(idx, 1), (const bf16*)dres, (bf16*)dx,
+                                                                (bf16*)dx2, R, d, pd, seed, extra);
     };
 
     // softmax backward: dlogits[step] (compute dtype, padded columns stay zero)
@@ -563,7 +610,7 @@ static int step_bwd(const Ctx& c, int step) {
         return rc;
     char* dx = G.dX();                         // running gradient of the residual stream [R,d]
     char* tmp = G.tmp();
-    ln_bwd(dnf, G.X(NL), p->lnF_g, NL * 3, nullptr, dx);
+    ln_bwd(dnf, G.X(NL), p->lnF_g, NL * 3, nullptr, dx, G.dact(NL - 1, G_DF2, step), site_seed(c, step, NL - 1, 6), 1.f);
     for (int l = NL - 1; l >= 0; --l) {
         const mssr_dec_layer& L = p->layers[l];
         char *h1 = G.act(l, K_H1), *qc = G.act(l, K_QC), *h2 = G.act(l, K_H2);
@@ -575,9 +622,8 @@ static int step_bwd(const Ctx& c, int step) {
         char* qkv_0 = G.qkv(l, 0);
         char* qkv_s = G.qkv(l, step);
         char* dqkv_s = G.dqkv(l, step);
-        // --- feed forward block: y = h2 + drop(W2 inter + b2), inter = drop(relu(W1 n3 + b1))
-        if (pd > 0.f) drop_replay(dx, d_f2, Rd, site_seed(c, step, l, 6), 1.f);
-        else (void)hipMemcpyAsync(d_f2, dx, Rd * es, hipMemcpyDeviceToDevice, c.s);
+        // --- feed forward block: y = h2 + drop(W2 inter + b2), inter = drop(relu(W1 n3 + b1));
+        //     d_f2 (gradient of the W2 output) was written by the LayerNorm backward above this layer
         // d_f1 = (d_f2 . W2) * (inter > 0) / (1-p)      [W as [N=ff, K=d] = wt_2]
         if ((rc = gemm_nt(c, d_f2, d, L.wt_2, d, d_f1, ff, R, ff, d, nullptr, 0, nullptr, 0, inter, ff, keep, 0.f, c.dt,
                           0.f, 0)))
@@ -585,10 +631,8 @@ static int step_bwd(const Ctx& c, int step) {
         if ((rc = gemm_nt(c, d_f1, ff, L.wt_1, ff, dn3, d, R, d, ff, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;
-        ln_bwd(dn3, h2, L.lnf_g, l * 3 + 2, dx, dx);                     // dx <- grad wrt h2
+        ln_bwd(dn3, h2, L.lnf_g, l * 3 + 2, dx, dx, d_co, site_seed(c, step, l, 4), 1.f);   // dx <- grad wrt h2
         // --- context attention block: h2 = h1 + drop(Wco ctx2 + bco)
-        if (pd > 0.f) drop_replay(dx, d_co, Rd, site_seed(c, step, l, 4), 1.f);
-        else (void)hipMemcpyAsync(d_co, dx, Rd * es, hipMemcpyDeviceToDevice, c.s);
         if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, tmp, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;                                                    // tmp = dctx2
@@ -603,10 +647,8 @@ static int step_bwd(const Ctx& c, int step) {
         if ((rc = gemm_nt(c, d_cq, d, L.wt_cq, d, dn2, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;
-        ln_bwd(dn2, h1, L.ln2_g, l * 3 + 1, dx, dx);                     // dx <- grad wrt h1
+        ln_bwd(dn2, h1, L.ln2_g, l * 3 + 1, dx, dx, d_so, site_seed(c, step, l, 2), 1.f);   // dx <- grad wrt h1
         // --- self attention block: h1 = x + drop(Wso ctx1 + bso)
-        if (pd > 0.f) drop_replay(dx, d_so, Rd, site_seed(c, step, l, 2), 1.f);
-        else (void)hipMemcpyAsync(d_so, dx, Rd * es, hipMemcpyDeviceToDevice, c.s);
         if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, tmp, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;                                                    // tmp = dctx1
@@ -620,14 +662,16 @@ static int step_bwd(const Ctx& c, int step) {
         if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))
             return rc;
-        ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dx, dx);                 // dx <- grad wrt layer input
+        // dx <- grad wrt the layer input; below it sits layer l-1's W2 output, or (l = 0) the embedding
+        // x0 = drop(e*sqrt(d) + pe), whose gradient d_e also takes the sqrt(d)
+        if (l > 0)
+            ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dx, dx, G.dact(l - 1, G_DF2, step), site_seed(c, step, l - 1, 6),
+                   1.f);
+        else
+            ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dx, dx, G.rows(p->d_e, step, d), site_seed(c, step, -1, 0),
+                   sqrtf((float)d));
     }
-    // embedding: x0 = drop(e*sqrt(d) + pe)  ->  d_e ; feedback into the previous step's probabilities
     char* de = G.rows(p->d_e, step, d);
-    if (pd > 0.f) drop_replay(dx, de, Rd, site_seed(c, step, -1, 0), sqrtf((float)d));
-    else {
-        if ((rc = mssr_axpby(dx, nullptr, de, Rd, sqrtf((float)d), 0.f, c.dt, c.s))) return rc;
-    }
     if (step > 0) {
         float* dprev = p->dprobs + ((int64_t)(step - 1) * B + G.r0) * p->V;
         // dprobs[step-1] += d_e . E^T      (W as [N=V, K=d] = E itself)

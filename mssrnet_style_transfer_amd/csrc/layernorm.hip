@@ -138,15 +138,34 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const T* __restrict__ 
     for (int i = threadIdx.x; i < 2 * d; i += LN_BLOCK) out[i] = smem[i];
 }
 
-// sums `parts` rows of width `w` and scatters columns [0,d) to out0, [d,2d) to out1
-__global__ void ln_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out0,
-                                   float* __restrict__ out1, int parts, int w, int d) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= w) return;
-    float s = 0.f;
-    for (int p = 0; p < parts; ++p) s += partial[(int64_t)p * w + c];
-    if (c < d) out0[c] = s;
-    else out1[c - d] = s;
+// sums `parts` rows of width `w` and scatters columns [0,d) to out0, [d,2d) to out1.
+// 16 columns x 16 part-groups per block: every thread has its (<= 16) loads in flight at once, so the
+// reduction is one memory round trip instead of a `parts`-long dependent chain.
+__global__ __launch_bounds__(256) void ln_finalize_kernel(const float* __restrict__ partial, float* __restrict__ out0,
+                                                          float* __restrict__ out1, int parts, int w, int d) {
+    __shared__ float sm[16][17];
+    const int cx = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (c < w) {
+        int p = g;
+        for (; p + 48 < parts; p += 64) {
+            s0 += partial[(int64_t)p * w + c];
+            s1 += partial[(int64_t)(p + 16) * w + c];
+            s2 += partial[(int64_t)(p + 32) * w + c];
+            s3 += partial[(int64_t)(p + 48) * w + c];
+        }
+        for (; p < parts; p += 16) s0 += partial[(int64_t)p * w + c];
+    }
+    sm[g][cx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (g == 0 && c < w) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += sm[i][cx];
+        if (c < d) out0[c] = t;
+        else out1[c - d] = t;
+    }
 }
 
 // Backward of ln_bwd: see include/mssr_hip.h.  With xhat, a = gamma*dy, c1 = mean(a),
@@ -334,7 +353,7 @@ extern "C" int mssr_layernorm_bwd(const void* dy, const void* x, const float* ga
             ln_bwd_kernel<bf16, NV><<<dim3(parts), dim3(LN_BLOCK), shm, s>>>(
                 (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)dx, partial, rows, d);
     });
-    ln_finalize_kernel<<<dim3((2 * d + 255) / 256), dim3(256), 0, s>>>(partial, dgamma, dbeta, parts, 2 * d, d);
+    ln_finalize_kernel<<<dim3((2 * d + 15) / 16), dim3(256), 0, s>>>(partial, dgamma, dbeta, parts, 2 * d, d);
     MSSR_LAUNCH_OK("layernorm_bwd");
 }
 
@@ -367,6 +386,6 @@ extern "C" int mssr_layernorm_bwd_bwd(const void* ggx, const float* ggg, const f
                 (const bf16*)ggx, ggg, ggb, (const bf16*)dy, (const bf16*)x, gamma, mean, rstd, (bf16*)g_dy,
                 (bf16*)g_x, partial, rows, d);
     });
-    ln_finalize_kernel<<<dim3((d + 255) / 256), dim3(256), 0, s>>>(partial, g_gamma, g_gamma, parts, d, d);
+    ln_finalize_kernel<<<dim3((d + 15) / 16), dim3(256), 0, s>>>(partial, g_gamma, g_gamma, parts, d, d);
     MSSR_LAUNCH_OK("layernorm_bwd_bwd");
 }

@@ -98,11 +98,29 @@ class _Pack:
             self.wt_gen[:, :V] = self.w_gen.t()
             self.b_gen = bg.detach().float().contiguous()
             self.lnF_g, self.lnF_b = lnFg.detach().float().contiguous(), lnFb.detach().float().contiguous()
+            # LayerNorm folded into the Linear behind it (bf16 skinny kernel, mssr_gemm_desc.ln_colsum):
+            # W' = gamma * W (rounded to bf16), colsum(W') of the ROUNDED values, bias' = W beta + b
+            self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
+            names = ["w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2",
+                     "wt_2", "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                     "lnf_g", "lnf_b"]
+            if self.fuse_ln:
+                def fold(idx, n_out, g, b, bias):
+                    w32 = rows(idx).float().view(NL, n_out, d)
+                    wg = (w32 * g.unsqueeze(1)).to(cd).contiguous()
+                    return wg, wg.float().sum(-1).contiguous(), (torch.bmm(w32, b.unsqueeze(2)).squeeze(2) + bias).contiguous()
+
+                self.wg_qkv, self.cs_qkv, self.bf_qkv = fold([_WQ, _WK, _WV], 3 * d, self.ln1_g, self.ln1_b, self.b_qkv)
+                self.wg_cq, self.cs_cq, self.bf_cq = fold([_WCQ], d, self.ln2_g, self.ln2_b, self.b_cq)
+                self.wg_1, self.cs_1, self.bf_1 = fold([_W1], ff, self.lnf_g, self.lnf_b, self.b_1)
+                wg32 = Wg.detach().float()
+                self.wg_gen = (wg32 * self.lnF_g).to(cd).contiguous()
+                self.cs_gen = self.wg_gen.float().sum(-1).contiguous()
+                self.bf_gen = (wg32 @ self.lnF_b + self.b_gen).contiguous()
+                names += ["wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1"]
         arr = (L.DecLayer * NL)()
         for l in range(NL):
-            for name in ("w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2",
-                         "wt_2", "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
-                         "lnf_g", "lnf_b"):
+            for name in names:
                 setattr(arr[l], name, getattr(self, name)[l].data_ptr())
         self.layers = arr
 
@@ -173,7 +191,9 @@ class _SoftDecode(Function):
         plan.n_chunks = max(1, min(8, int(os.environ.get("MSSR_DECODE_CHUNKS", "1")), B))
         plan.p_drop, plan.p_attn, plan.temperature, plan.seed = spec.p_drop, spec.p_attn, spec.temperature, spec.seed
         plan.layers = pk.layers
-        for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b"):
+        plan.fuse_ln = int(pk.fuse_ln and os.environ.get("MSSR_DECODE_FUSE_LN", "1") != "0")
+        for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b") + (
+                ("wg_gen", "cs_gen", "bf_gen") if pk.fuse_ln else ()):
             setattr(plan, name, getattr(pk, name).data_ptr())
         plan.pe = spec.pe.data_ptr()
         plan.src_mask = spec.src_mask.data_ptr()
@@ -212,6 +232,20 @@ class _SoftDecode(Function):
         L.check(lib.mssr_decode_bwd(ctypes.byref(plan), L.stream()), "decode_bwd")
 
         actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
+        stats = bufs["stats"]
+        if plan.fuse_ln:
+            # the forward normalised inside the projections: materialise LN outputs once, over all steps' rows
+            sm, sr = e(R, dtype=torch.float32), e(R, dtype=torch.float32)
+
+            def ln_fwd(x, gam, bet, y):
+                L.check(lib.mssr_layernorm_fwd(x.data_ptr(), gam.data_ptr(), bet.data_ptr(), y.data_ptr(), sm.data_ptr(),
+                                               sr.data_ptr(), R, d, 1e-6, plan.dtype, L.stream()), "layernorm_fwd")
+
+            for l in range(NL):
+                ln_fwd(X[l], pk.ln1_g[l], pk.ln1_b[l], actD[l, K_N1])
+                ln_fwd(actD[l, K_H1], pk.ln2_g[l], pk.ln2_b[l], actD[l, K_N2])
+                ln_fwd(actD[l, K_H2], pk.lnf_g[l], pk.lnf_b[l], actD[l, K_N3])
+            ln_fwd(X[NL], pk.lnF_g, pk.lnF_b, bufs["nf"])
         gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, K_N1]), _bsum(dqkv)
         gW_so, gb_so = _bgemm_t(dactD[:, G_DSO], actD[:, K_CTX1]), _bsum(dactD[:, G_DSO])
         gW_cq, gb_cq = _bgemm_t(dactD[:, G_DCQ], actD[:, K_N2]), _bsum(dactD[:, G_DCQ])
@@ -227,7 +261,6 @@ class _SoftDecode(Function):
             shape, dtype = ctx.mem_meta
             g_mem = ops.gemm(dmem_kv, pk.w_ckv, False, cd).view(shape).to(dtype)
         # LayerNorm gains / biases: sum over all (step, sentence) rows
-        stats = bufs["stats"]
         parts = lib.mssr_layernorm_partial_rows(R)
         ws = e(2 * parts * d, dtype=torch.float32)
         scratch = e(R, d)
