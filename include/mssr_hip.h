@@ -255,8 +255,13 @@ typedef struct {
     void* dqkv;                   /* [n_layers][T][B, 3d] */
     void* dactD;                  /* [n_layers][7][T][B, d]  dn1|d_so|dn2|d_cq|d_co|dn3|d_f2 */
     void* dactF;                  /* [n_layers][T][B, ff]    d_f1 */
-    float* dkv_acc;               /* [n_layers][T][B, 2d] zeroed by the caller */
-    float* dmem_acc;              /* [B, Ls, n_layers, 2d] zeroed by the caller: dL/d mem_kv */
+    void* dctx;                   /* [n_layers][2][T][B, d] gradients of the self / context attention outputs */
+    float* ds_self;               /* [n_layers][2][T][B*heads][T]: per step s, score gradients ds_s[t] and dropped
+                                   * probabilities pd_s[t] (t <= s) of the self attention; key / value gradients
+                                   * are gathered from these (dK[t] = sum_{s>=t} ds_s[t] q_s, ...) */
+    float* ds_ctx;                /* [n_layers][2][T][B*heads][Ls]: the same for the context attention; the caller
+                                   * contracts them over the steps: dL/d mem K = sum_s ds_s (x) qc_s,
+                                   * dL/d mem V = sum_s pd_s (x) dctx_s */
     void* d_e;                    /* [T][B, d] gradient of the soft-embedding product */
     void* dnf;                    /* [T][B, d] */
 } mssr_decode_plan;
@@ -265,7 +270,7 @@ typedef struct {
 int mssr_decode_step_fwd(const mssr_decode_plan* plan, int step, void* stream);
 /* Its backward; call for step = T-1 .. 0.  Leaves the gradient of every GEMM output in the d*
  * slabs (the caller contracts them with the saved activations into parameter gradients, one
- * product per parameter over all steps) and dL/d mem_kv in dmem_acc. */
+ * product per parameter over all steps) and the context-attention score gradients in ds_ctx. */
 int mssr_decode_step_bwd(const mssr_decode_plan* plan, int step, void* stream);
 /* All steps in one call. */
 int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);

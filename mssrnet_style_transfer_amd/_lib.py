@@ -51,8 +51,8 @@ class DecodePlan(Structure):
                                            "wg_gen", "cs_gen", "bf_gen", "mem_kv", "src_mask", "in_all", "probs", "X", "qkv", "actD", "actF",
                                            "stats", "nf", "logits", "tmp", "gemm_ws")]
                 + [("gemm_ws_bytes", c_int64)]
-                + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dkv_acc",
-                                           "dmem_acc", "d_e", "dnf")])
+                + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dctx",
+                                           "ds_self", "ds_ctx", "d_e", "dnf")])
 
 
 class ProfRecord(Structure):

@@ -79,21 +79,26 @@ __global__ __launch_bounds__(256) void attn_step_fwd_kernel(
     }
 }
 
-// Backward of the above for one step.  Recomputes the probabilities (fp32) from q and K, then
-//   dp = dctx.V^T (x dropout) ; ds = p (dp - sum p dp) scale ; dq = ds.K ;
-//   dK_acc[t] += ds_t q ; dV_acc[t] += pd_t dctx      (fp32 accumulators, one wave owns its (b,h) slice)
-// If fin_row >= 0 the accumulated row `fin_row` of dK/dV is final (no later step touches it) and is
-// written in the storage dtype to dk_out/dv_out (the slot of the packed dqkv slab for that step).
+// Backward of the above for one step s.  Recomputes the probabilities (fp32) from q and K, then
+//   dp = dctx.V^T (x dropout) ; ds = p (dp - sum p dp) scale ; dq = ds.K
+// and leaves ds_t and pd_t = dropped p_t (what multiplied V) in the per-step slabs ds_out / pd_out [Lk]:
+// key/value gradients are GATHERED from those slabs, never accumulated in memory --
+//   dK[t] = sum_{s >= t} ds_s[t] q_s ,  dV[t] = sum_{s >= t} pd_s[t] dctx_s .
+// Self attention (gather != 0): row t = s of K/V is final once step s runs (later steps ran before it
+// in the reverse sweep), so this launch also forms dK[s], dV[s] from the slabs of steps s .. T-1
+// (stride slab_ss between steps), the q rows of the packed cache (stride q_ss) and the saved dctx rows
+// (stride dctx_ss), and writes them into the dqkv slot of step s.  Context attention: the caller
+// contracts the slabs over all steps at the end (one batched product per layer).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
-    T* __restrict__ dq, int64_t dq_bs, float* __restrict__ dk_acc, float* __restrict__ dv_acc, int64_t acc_bs,
-    int64_t acc_ts, int fin_row, T* __restrict__ dk_out, T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh,
-    int Lk, float scale, float p_drop, uint64_t seed) {
+    T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
+    int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
+    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
     __shared__ float s_p[4][AT_MAXK];      // p, then ds
-    __shared__ float s_pd[4][AT_MAXK];     // dropped p (what multiplied V in the forward)
-    __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p)
+    __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p); then the gathered ds coefficients of later steps
+    __shared__ float s_pd[4][AT_MAXK];     // dropped p; then the gathered pd coefficients of later steps
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bh_raw = blockIdx.x * 4 + wave;
     const bool active = bh_raw < B * H;
@@ -103,9 +108,11 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     const T* kp = k + (int64_t)b * kv_bs + h * dh;
     const T* vp = v + (int64_t)b * kv_bs + h * dh;
     const T* dcp = dctx + (int64_t)b * dctx_bs + h * dh;
+    float* dso = ds_out + (int64_t)bh * slab_bhs;
+    float* pdo = pd_out + (int64_t)bh * slab_bhs;
     float* s = s_p[wave];
-    float* pd = s_pd[wave];
     float* dpv = s_dp[wave];
+    float* pdv = s_pd[wave];
     float mx = -INFINITY;
     for (int t = lane; t < Lk; t += 64) {
         const T* kr = kp + (int64_t)t * kv_ts;
@@ -148,8 +155,9 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
         }
         const float dp = a * m;
         s[t] = p;
-        pd[t] = p * m;
         dpv[t] = dp;
+        pdv[t] = p * m;
+        if (active) pdo[t] = p * m;
         r += p * dp;
     }
     r = wave_sum(r);
@@ -157,29 +165,35 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
         float ds = s[t] * (dpv[t] - r) * scale;
         if (mask && mask[(int64_t)b * mask_bs + t]) ds = 0.f;     // masked_fill: no gradient to the score
         s[t] = ds;
+        if (active) dso[t] = ds;
+    }
+    __syncthreads();
+    const float pd_own = gather ? pdv[step] : 0.f;
+    __syncthreads();
+    // coefficients of row `step` in the slabs of steps step+1 .. T-1 (slab of step s' sits (s'-step)*slab_ss on)
+    const int n_later = gather ? n_steps - 1 - step : 0;
+    for (int i = lane; i < n_later; i += 64) {
+        dpv[i] = dso[(int64_t)(i + 1) * slab_ss + step];
+        pdv[i] = pdo[(int64_t)(i + 1) * slab_ss + step];
     }
     __syncthreads();
     if (!active) return;
-    // lane <-> feature: dq, dK, dV
+    // lane <-> feature: dq (and the gathered dK, dV of row `step`)
     for (int j = lane; j < dh; j += 64) {
-        const float qj = to_f(qp[j]);
-        const float dcj = to_f(dcp[j]);
         float a = 0.f;
-        float* dkp = dk_acc + (int64_t)b * acc_bs + h * dh + j;
-        float* dvp = dv_acc + (int64_t)b * acc_bs + h * dh + j;
-        for (int t = 0; t < Lk; ++t) {
-            const float ds = s[t];
-            a += ds * to_f(kp[(int64_t)t * kv_ts + j]);
-            const float nk = dkp[(int64_t)t * acc_ts] + ds * qj;
-            const float nv = dvp[(int64_t)t * acc_ts] + pd[t] * dcj;
-            dkp[(int64_t)t * acc_ts] = nk;
-            dvp[(int64_t)t * acc_ts] = nv;
-            if (t == fin_row) {
-                dk_out[(int64_t)b * out_bs + h * dh + j] = from_f<T>(nk);
-                dv_out[(int64_t)b * out_bs + h * dh + j] = from_f<T>(nv);
-            }
-        }
+        for (int t = 0; t < Lk; ++t) a += s[t] * to_f(kp[(int64_t)t * kv_ts + j]);
         dq[(int64_t)b * dq_bs + h * dh + j] = from_f<T>(a);
+        if (gather) {
+            // own step: ds_step[step] q_step, pd_step[step] dctx_step; then the later steps
+            float gk = s[step] * to_f(qp[j]);
+            float gv = pd_own * to_f(dcp[j]);
+            for (int i = 0; i < n_later; ++i) {
+                gk += dpv[i] * to_f(qp[(int64_t)(i + 1) * q_ss + j]);
+                gv += pdv[i] * to_f(dcp[(int64_t)(i + 1) * dctx_ss + j]);
+            }
+            dk_out[(int64_t)b * out_bs + h * dh + j] = from_f<T>(gk);
+            dv_out[(int64_t)b * out_bs + h * dh + j] = from_f<T>(gv);
+        }
     }
 }
 
@@ -369,16 +383,16 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
 template <typename T>
 static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const void* k, const void* v, int64_t kv_bs,
                             int64_t kv_ts, const uint8_t* mask, int64_t mask_bs, const void* dctx, int64_t dctx_bs,
-                            void* dq, int64_t dq_bs, float* dk_acc, float* dv_acc, int64_t acc_bs, int64_t acc_ts,
-                            int fin_row, void* dk_out, void* dv_out, int64_t out_bs, int Lk, float p_drop,
-                            uint64_t seed) {
+                            void* dq, int64_t dq_bs, float* ds_out, float* pd_out, int64_t slab_bhs, int gather,
+                            int step, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, void* dk_out, void* dv_out,
+                            int64_t out_bs, int Lk, float p_drop, uint64_t seed) {
     const mssr_decode_plan* p = c.p;
     const int dh = p->d / p->heads;
     const int bh = c.Bc * p->heads;
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
-        dq_bs, dk_acc, dv_acc, acc_bs, acc_ts, fin_row, (T*)dk_out, (T*)dv_out, out_bs, c.Bc, p->heads, dh, Lk,
-        1.0f / sqrtf((float)dh), p_drop, seed);
+        dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
 }
 
 #define DT_CALL(c, fn, ...)                                   \
@@ -449,9 +463,15 @@ struct Geo {
     char* dact(int l, int kind, int step) const { return rows(p->dactD, ((int64_t)l * G_NKINDS + kind) * T + step, d); }
     char* dinter(int l, int step) const { return rows(p->dactF, (int64_t)l * T + step, ff); }
     char* dqkv(int l, int step) const { return rows(p->dqkv, (int64_t)l * T + step, 3 * d); }
-    float* kv_acc(int l) const { return p->dkv_acc + ((int64_t)l * T * B + r0) * 2 * d; }          // step 0 block
+    char* dctx(int l, int which, int step) const { return rows(p->dctx, ((int64_t)l * 2 + which) * T + step, d); }
+    // per-step score-gradient slabs [n_layers][2 = ds|pd][T][B*H][W], W = T (self) or Ls (context)
+    float* ds_self(int l, int which, int step) const {
+        return p->ds_self + ((((int64_t)l * 2 + which) * T + step) * B + r0) * p->heads * T;
+    }
+    float* ds_ctx(int l, int which, int step) const {
+        return p->ds_ctx + ((((int64_t)l * 2 + which) * T + step) * B + r0) * p->heads * Ls;
+    }
     const char* mem_kv(int l) const { return at((void*)p->mem_kv, ((int64_t)r0 * Ls * NL + l) * 2 * d, es); }
-    float* mem_acc(int l) const { return p->dmem_acc + ((int64_t)r0 * Ls * NL + l) * 2 * d; }
     const uint8_t* src_mask() const { return p->src_mask + (int64_t)r0 * Ls; }
     char* tmp() const { return at(p->tmp, (int64_t)r0 * d, es); }
     char* logits() const { return at(p->logits, (int64_t)r0 * Vp, es); }
@@ -609,7 +629,6 @@ static int step_bwd(const Ctx& c, int step) {
                       0.f, c.dt, 0.f, 0)))
         return rc;
     char* dx = G.dX();                         // running gradient of the residual stream [R,d]
-    char* tmp = G.tmp();
     ln_bwd(dnf, G.X(NL), p->lnF_g, NL * 3, nullptr, dx, G.dact(NL - 1, G_DF2, step), site_seed(c, step, NL - 1, 6), 1.f);
     for (int l = NL - 1; l >= 0; --l) {
         const mssr_dec_layer& L = p->layers[l];
@@ -633,15 +652,15 @@ static int step_bwd(const Ctx& c, int step) {
             return rc;
         ln_bwd(dn3, h2, L.lnf_g, l * 3 + 2, dx, dx, d_co, site_seed(c, step, l, 4), 1.f);   // dx <- grad wrt h2
         // --- context attention block: h2 = h1 + drop(Wco ctx2 + bco)
-        if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, tmp, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+        char* dctx2 = G.dctx(l, 1, step);
+        if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, dctx2, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
-            return rc;                                                    // tmp = dctx2
+            return rc;
         {
             const char* mkv = G.mem_kv(l);
-            float* macc = G.mem_acc(l);                                   // [B, Ls, NL, 2d] float, layer l
             DT_CALL(c, launch_attn_bwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
-                    (int64_t)NL * 2 * d, G.src_mask(), p->Ls, tmp, d, d_cq, d, macc, macc + d,
-                    (int64_t)p->Ls * NL * 2 * d, (int64_t)NL * 2 * d, -1, nullptr, nullptr, 0, p->Ls, pa,
+                    (int64_t)NL * 2 * d, G.src_mask(), p->Ls, dctx2, d, d_cq, d, G.ds_ctx(l, 0, step),
+                    G.ds_ctx(l, 1, step), p->Ls, 0, step, 0, 0, 0, nullptr, nullptr, 0, p->Ls, pa,
                     site_seed(c, step, l, 3));
         }
         if ((rc = gemm_nt(c, d_cq, d, L.wt_cq, d, dn2, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
@@ -649,16 +668,14 @@ static int step_bwd(const Ctx& c, int step) {
             return rc;
         ln_bwd(dn2, h1, L.ln2_g, l * 3 + 1, dx, dx, d_so, site_seed(c, step, l, 2), 1.f);   // dx <- grad wrt h1
         // --- self attention block: h1 = x + drop(Wso ctx1 + bso)
-        if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, tmp, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
+        char* dctx1 = G.dctx(l, 0, step);
+        if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, dctx1, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
-            return rc;                                                    // tmp = dctx1
-        {
-            float* kacc = G.kv_acc(l);                                    // [T][B, 2d] float
-            DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
-                    (int64_t)B * 3 * d, nullptr, 0, tmp, d, dqkv_s, 3 * d, kacc, kacc + d, 2 * d, (int64_t)B * 2 * d,
-                    step, dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa,
-                    site_seed(c, step, l, 1));
-        }
+            return rc;
+        DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
+                (int64_t)B * 3 * d, nullptr, 0, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
+                p->T, 1, step, (int64_t)B * p->heads * p->T, (int64_t)B * 3 * d, (int64_t)B * d,
+                dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))
             return rc;
@@ -713,7 +730,7 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
     if (backward) {
         MSSR_REQUIRE(p->save, "%s: the forward did not save activations (save = 0)", who);
         MSSR_REQUIRE(p->emb && p->wt_gen && p->dprobs && p->dlogits && p->dX && p->dqkv && p->dactD && p->dactF &&
-                         p->dkv_acc && p->dmem_acc && p->d_e && p->dnf,
+                         p->dctx && p->ds_self && p->ds_ctx && p->d_e && p->dnf,
                      "%s: null gradient buffer in plan", who);
     }
     const int per = (p->B + p->n_chunks - 1) / p->n_chunks;

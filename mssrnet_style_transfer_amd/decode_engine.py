@@ -220,12 +220,14 @@ class _SoftDecode(Function):
         lib = L.load()
         cd, dev = pk.cd, dprobs.device
         B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
+        H = spec.heads
         R = T * B
         z = lambda *shape, dtype=cd: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
         g = dict(dprobs=dprobs.to(torch.float32).clone(memory_format=torch.contiguous_format),
                  dlogits=z(R, Vp), dX=e(B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
-                 dkv_acc=z(NL, R, 2 * d, dtype=torch.float32), dmem_acc=z(B * Ls, NL * 2 * d, dtype=torch.float32),
+                 dctx=e(NL, 2, R, d), ds_self=e(NL, 2, T, B * H, T, dtype=torch.float32),
+                 ds_ctx=e(NL, 2, T, B * H, Ls, dtype=torch.float32),
                  d_e=e(R, d), dnf=e(R, d))
         for name, t in g.items():
             setattr(plan, name, t.data_ptr())
@@ -252,8 +254,17 @@ class _SoftDecode(Function):
         gW_co, gb_co = _bgemm_t(dactD[:, G_DCO], actD[:, K_CTX2]), _bsum(dactD[:, G_DCO])
         gW_1, gb_1 = _bgemm_t(dactF, actD[:, K_N3]), _bsum(dactF)
         gW_2, gb_2 = _bgemm_t(dactD[:, G_DF2], actF), _bsum(dactD[:, G_DF2])
-        # context key/value projections of the memory bank: one product over all layers
-        dmem_kv = g["dmem_acc"].to(cd)
+        # gradient of the memory keys / values: contract the per-step score gradients over the steps,
+        #   dK_mem[b,h,l,:] = sum_s ds_s[b,h,l] qc_s[b,h,:] ,  dV_mem[b,h,l,:] = sum_s pd_s[b,h,l] dctx2_s[b,h,:]
+        # (one batched product per layer and operand), then the K|V projections in one product over all layers
+        dh = d // H
+        dmem_kv = e(B, Ls, NL, 2, H, dh)
+        dsc = g["ds_ctx"].to(cd).view(NL, 2, T, B, H, Ls)
+        for l in range(NL):
+            for which, rhs in ((0, actD[l, K_QC]), (1, g["dctx"][l, 1])):
+                ops.gemm(dsc[l, which].permute(1, 2, 3, 0), rhs.view(T, B, H, dh).permute(1, 2, 0, 3), False, cd,
+                         out=dmem_kv[:, :, l, which].permute(0, 2, 1, 3))
+        dmem_kv = dmem_kv.view(B * Ls, NL * 2 * d)
         gW_ckv = _bgemm_t(dmem_kv, bufs["mem"]).view(NL, 2 * d, d)
         gb_ckv = ops.gemm(torch.ones(1, B * Ls, dtype=cd, device=dev), dmem_kv, False, torch.float32).view(NL, 2 * d)
         g_mem = None
