@@ -86,13 +86,13 @@ typedef struct {
      * hash as mssr_dropout_fwd, so a backward pass can regenerate the mask from the seed. */
     float drop_p;
     uint64_t drop_seed;
-    /* optional fp32 scratch for the split-K slabs of the skinny-M kernel (m <= 128, k > 2048):
+    /* optional fp32 scratch for the split-K slabs of the K-split kernel (k > 2048):
      * ceil(k/2048) * m * n floats.  NULL: such problems use the general kernel. */
     void* workspace;
     int64_t workspace_bytes;
     int no_skinny;   /* 1 = always use the general tiled kernel */
     /* LayerNorm folded into the product (`LN -> Linear`, onmt/decoders/transformer.py:150-157,
-     * onmt/modules/position_ffn.py:35), skinny kernel only (bf16, m <= 128, k <= 2048): when ln_colsum
+     * onmt/modules/position_ffn.py:35), K-split kernel only (bf16, m <= 8192, k <= 2048): when ln_colsum
      * is non-NULL, A holds the RAW rows x, B holds gamma-scaled weights W'[n,k] = gamma[k] W[n,k],
      * ln_colsum[n] = sum_k W'[n,k], bias[n] = sum_k beta[k] W[n,k] + b[n], and the result is
      *   rstd_m (acc - mean_m ln_colsum[n]) + bias[n]  ( = LN(x) W^T + b ), then the usual epilogue.
@@ -106,10 +106,10 @@ int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
 /* Block tile edge (64 or 32) mssr_gemm picks for an m x n x batch problem; lets a profiler name the
  * kernel instance (gemm_kernel<.., 64, 64> / <.., 32, 32>) a launch used.  No reference counterpart. */
 int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);
-/* 1 when mssr_gemm would route `desc` to the skinny-M kernel (m <= 128, bf16, both operands
- * k-contiguous and 16-byte aligned, k a multiple of 32): C = A[m,k] . W[n,k]^T, one block per 16x16
- * output tile, its four waves splitting K and loading straight into MFMA fragments.  No reference
- * counterpart. */
+/* 1 when mssr_gemm would route `desc` to the K-split ("skinny") kernel (m <= 8192, bf16, both
+ * operands k-contiguous and 16-byte aligned, k a multiple of 32): C = A[m,k] . W[n,k]^T, one block
+ * per 16x16 (m <= 128) or 32x32 output tile, its four waves splitting K and loading straight into
+ * MFMA fragments -- a single memory round trip per launch.  No reference counterpart. */
 int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
 
 /* Launch timing for the benchmark's roofline (no reference counterpart): between mssr_prof_start

@@ -198,7 +198,7 @@ static void fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
     a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
     a.ksplit = 1;
     a.partial = nullptr;
-    if (d->workspace && d->m <= 128 && d->k > 32 * 64) {
+    if (d->workspace && d->k > 32 * 64) {
         const int64_t need = gemm_skinny_ksplit(d->k) * d->m * d->n * (int64_t)sizeof(float);
         if (d->workspace_bytes >= need && aligned(d->workspace, 16)) a.partial = (float*)d->workspace;
     }
@@ -248,7 +248,7 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
         MSSR_LAUNCH_OK("gemm(skinny)");
     }
     if (d->ln_colsum) {
-        set_error("gemm: the LayerNorm prologue needs the skinny kernel (bf16, m <= 128, k <= 2048, k %% 32 == 0, "
+        set_error("gemm: the LayerNorm prologue needs the K-split kernel (bf16, m <= 8192, k <= 2048, k %% 32 == 0, "
                   "k-contiguous 16-byte aligned operands)");
         return MSSR_ERR_UNSUPPORTED;
     }

@@ -25,13 +25,18 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SK_THREADS = 256;
 constexpr int SK_GROUP = 4;          // k-steps (of 32) in flight per wave
 constexpr int SK_MAX_STEPS = 64;     // k-steps per block without split-K (K <= 2048)
+constexpr int SK_MAX_M = 8192;       // above this the general LDS-tiled kernel (operand reuse) takes over
 
-template <typename TO, bool LN>
+// F = fragments per tile edge: F = 1 -> 16x16 tile (M <= 128), F = 2 -> 32x32 tile (larger M)
+template <typename TO, bool LN, int F>
 __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4 * 256];
-    __shared__ float stat[4][16][2];
+    constexpr int TS = 16 * F;                 // tile edge
+    constexpr int TE = TS * TS;                // tile elements
+    constexpr int EPT = TE / SK_THREADS;       // epilogue elements per thread (1 or 4)
+    __shared__ __attribute__((aligned(16))) float red[4 * TE];
+    __shared__ float stat[4][TS][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n0 = (int64_t)blockIdx.x * 16, m0 = (int64_t)blockIdx.y * 16;
+    const int64_t n0 = (int64_t)blockIdx.x * TS, m0 = (int64_t)blockIdx.y * TS;
     const int split = blockIdx.z;
     const int64_t steps_total = p.k / 32;
     const int64_t per = (steps_total + p.ksplit - 1) / p.ksplit;
@@ -41,27 +46,45 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     const bf16* A = reinterpret_cast<const bf16*>(p.a);
     const bf16* W = reinterpret_cast<const bf16*>(p.b);
     const int koff = 8 * (lane >> 4);
-    const int64_t ar = m0 + (lane & 15), wn = n0 + (lane & 15);
-    const int64_t arow = (ar < p.m ? ar : p.m - 1) * p.a_rs;
-    const int64_t wrow = (wn < p.n ? wn : p.n - 1) * p.b_cs;     // B viewed [k,n]: n stride = b_cs
-
-    // the element this thread finishes, and its epilogue operands (issued before the main loads)
-    const int64_t erow = m0 + (threadIdx.x >> 4), ecol = n0 + (threadIdx.x & 15);
-    const bool eok = erow < p.m && ecol < p.n;
-    float bias = 0.f, res = 0.f, gate = 1.f, cold = 0.f, lns = 0.f;
-    if (eok && p.ksplit == 1) {
-        if (p.bias) bias = p.bias[ecol];
-        if (p.residual) res = to_f(reinterpret_cast<const bf16*>(p.residual)[erow * p.ldr + ecol]);
-        if (p.gate) gate = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol]);
-        if (p.beta != 0.f) cold = to_f(reinterpret_cast<const TO*>(p.c)[erow * p.ldc + ecol]);
-        if (LN) lns = p.ln_colsum[ecol];
+    int64_t arow[F], wrow[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) {
+        const int64_t ar = m0 + f * 16 + (lane & 15), wn = n0 + f * 16 + (lane & 15);
+        arow[f] = (ar < p.m ? ar : p.m - 1) * p.a_rs;
+        wrow[f] = (wn < p.n ? wn : p.n - 1) * p.b_cs;            // B viewed [k,n]: n stride = b_cs
     }
 
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    float sx = 0.f, sxx = 0.f;
+    // the elements this thread finishes (tile-local index e = threadIdx.x + i*256: row e / TS, col e % TS),
+    // and their epilogue operands, issued before the main loads
+    float bias[EPT], res[EPT], gate[EPT], cold[EPT], lns[EPT];
+    bool eok[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + i * SK_THREADS;
+        const int64_t erow = m0 + e / TS, ecol = n0 + e % TS;
+        eok[i] = erow < p.m && ecol < p.n;
+        bias[i] = res[i] = cold[i] = lns[i] = 0.f;
+        gate[i] = 1.f;
+        if (eok[i] && p.ksplit == 1) {
+            if (p.bias) bias[i] = p.bias[ecol];
+            if (p.residual) res[i] = to_f(reinterpret_cast<const bf16*>(p.residual)[erow * p.ldr + ecol]);
+            if (p.gate) gate[i] = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol]);
+            if (p.beta != 0.f) cold[i] = to_f(reinterpret_cast<const TO*>(p.c)[erow * p.ldc + ecol]);
+            if (LN) lns[i] = p.ln_colsum[ecol];
+        }
+    }
+
+    f32x4 acc[F][F];
+#pragma unroll
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx[F], sxx[F];
+#pragma unroll
+    for (int f = 0; f < F; ++f) sx[f] = sxx[f] = 0.f;
     // wave w owns k-steps s_begin + w, + 4, + 8 ... ; SK_GROUP of them in flight at a time
     for (int64_t s0 = s_begin + wave; s0 < s_end; s0 += 4 * SK_GROUP) {
-        bf16x8 fa[SK_GROUP], fb[SK_GROUP];
+        bf16x8 fa[SK_GROUP][F], fb[SK_GROUP][F];
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
             // unconditional loads (clamped to the last valid k-step): a branch around a load makes
@@ -69,71 +92,94 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             int64_t s = s0 + 4 * g;
             s = s < s_end ? s : s_end - 1;
             const int64_t k = s * 32 + koff;
-            fb[g] = *reinterpret_cast<const bf16x8*>(W + wrow + k);
-            fa[g] = *reinterpret_cast<const bf16x8*>(A + arow + k);
+#pragma unroll
+            for (int f = 0; f < F; ++f) {
+                fb[g][f] = *reinterpret_cast<const bf16x8*>(W + wrow[f] + k);
+                fa[g][f] = *reinterpret_cast<const bf16x8*>(A + arow[f] + k);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the whole batch of loads ahead of the first MFMA
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
-            // k-steps past the end were loaded from a clamped address: zero the weight fragment with a
+            // k-steps past the end were loaded from a clamped address: zero the weight fragments with a
             // bit mask (no branch, so the loads above stay one batch in flight)
             const bool live = s0 + 4 * g < s_end;
             const unsigned msk = live ? 0xffffffffu : 0u;
-            u32x4 wb = __builtin_bit_cast(u32x4, fb[g]);
-            wb &= msk;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g], __builtin_bit_cast(bf16x8, wb), acc, 0, 0, 0);
+#pragma unroll
+            for (int j = 0; j < F; ++j) {
+                u32x4 wb = __builtin_bit_cast(u32x4, fb[g][j]);
+                wb &= msk;
+                const bf16x8 fbm = __builtin_bit_cast(bf16x8, wb);
+#pragma unroll
+                for (int i = 0; i < F; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g][i], fbm, acc[i][j], 0, 0, 0);
+            }
             if (LN && live) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float x = (float)fa[g][j];
-                    sx += x;
-                    sxx += x * x;
-                }
+                for (int f = 0; f < F; ++f)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = (float)fa[g][f][j];
+                        sx[f] += x;
+                        sxx[f] += x * x;
+                    }
             }
         }
     }
-    // partial tiles -> LDS as [wave][row*16 + col]  (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
+    // partial tiles -> LDS as [wave][row*TS + col]  (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave * 256 + ((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+    for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[wave * TE + (i * 16 + (lane >> 4) * 4 + r) * TS + j * 16 + (lane & 15)] = acc[i][j][r];
     if (LN) {       // row sums: the 4 lanes (lane & 15, lane >> 4 = 0..3) of a wave hold one row's k-chunks
-        sx += __shfl_xor(sx, 16, 64);
-        sx += __shfl_xor(sx, 32, 64);
-        sxx += __shfl_xor(sxx, 16, 64);
-        sxx += __shfl_xor(sxx, 32, 64);
-        if (lane < 16) {
-            stat[wave][lane][0] = sx;
-            stat[wave][lane][1] = sxx;
+#pragma unroll
+        for (int f = 0; f < F; ++f) {
+            sx[f] += __shfl_xor(sx[f], 16, 64);
+            sx[f] += __shfl_xor(sx[f], 32, 64);
+            sxx[f] += __shfl_xor(sxx[f], 16, 64);
+            sxx[f] += __shfl_xor(sxx[f], 32, 64);
+            if (lane < 16) {
+                stat[wave][f * 16 + lane][0] = sx[f];
+                stat[wave][f * 16 + lane][1] = sxx[f];
+            }
         }
     }
     __syncthreads();
-    if (!eok) return;
-    const int t = threadIdx.x;
-    float v = (red[t] + red[256 + t]) + (red[512 + t] + red[768 + t]);
-    if (p.ksplit > 1) {
-        p.partial[((int64_t)split * p.m + erow) * p.n + ecol] = v;
-        return;
-    }
-    if (LN) {
-        const int rl = t >> 4;
-        const float s1 = (stat[0][rl][0] + stat[1][rl][0]) + (stat[2][rl][0] + stat[3][rl][0]);
-        const float s2 = (stat[0][rl][1] + stat[1][rl][1]) + (stat[2][rl][1] + stat[3][rl][1]);
-        const float mean = s1 / (float)p.k;
-        const float var = fmaxf(s2 / (float)p.k - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + p.ln_eps);
-        v = rstd * (v - mean * lns);
-        if (blockIdx.x == 0 && (t & 15) == 0) {
-            if (p.ln_mean) p.ln_mean[erow] = mean;
-            if (p.ln_rstd) p.ln_rstd[erow] = rstd;
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        if (!eok[i]) continue;
+        const int e = threadIdx.x + i * SK_THREADS;
+        const int rl = e / TS;
+        const int64_t erow = m0 + rl, ecol = n0 + e % TS;
+        float v = (red[e] + red[TE + e]) + (red[2 * TE + e] + red[3 * TE + e]);
+        if (p.ksplit > 1) {
+            p.partial[((int64_t)split * p.m + erow) * p.n + ecol] = v;
+            continue;
         }
+        if (LN) {
+            const float s1 = (stat[0][rl][0] + stat[1][rl][0]) + (stat[2][rl][0] + stat[3][rl][0]);
+            const float s2 = (stat[0][rl][1] + stat[1][rl][1]) + (stat[2][rl][1] + stat[3][rl][1]);
+            const float mean = s1 / (float)p.k;
+            const float var = fmaxf(s2 / (float)p.k - mean * mean, 0.f);
+            const float rstd = rsqrtf(var + p.ln_eps);
+            v = rstd * (v - mean * lns[i]);
+            if (blockIdx.x == 0 && (e % TS) == 0) {
+                if (p.ln_mean) p.ln_mean[erow] = mean;
+                if (p.ln_rstd) p.ln_rstd[erow] = rstd;
+            }
+        }
+        v = p.alpha * v + bias[i];
+        if (p.relu) v = fmaxf(v, 0.f);
+        if (p.drop_p > 0.f)
+            v = drop_keep(p.drop_seed, (uint64_t)(erow * p.n + ecol), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+        v += res[i];
+        if (p.gate) v = gate[i] > 0.f ? v : 0.f;
+        if (p.beta != 0.f) v += p.beta * cold[i];
+        reinterpret_cast<TO*>(p.c)[erow * p.ldc + ecol] = from_f<TO>(v);
     }
-    v = p.alpha * v + bias;
-    if (p.relu) v = fmaxf(v, 0.f);
-    if (p.drop_p > 0.f)
-        v = drop_keep(p.drop_seed, (uint64_t)(erow * p.n + ecol), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
-    v += res;
-    if (p.gate) v = gate > 0.f ? v : 0.f;
-    if (p.beta != 0.f) v += p.beta * cold;
-    reinterpret_cast<TO*>(p.c)[erow * p.ldc + ecol] = from_f<TO>(v);
 }
 
 template <typename TO>
@@ -152,9 +198,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const GemmArgs 
 
 template <typename TO>
 static void skinny_launch(const GemmArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
-    if (a.ln_colsum) gemm_skinny_kernel<TO, true><<<grid, SK_THREADS, 0, s>>>(a);
-    else gemm_skinny_kernel<TO, false><<<grid, SK_THREADS, 0, s>>>(a);
+    if (a.m <= 128) {
+        const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
+        if (a.ln_colsum) gemm_skinny_kernel<TO, true, 1><<<grid, SK_THREADS, 0, s>>>(a);
+        else gemm_skinny_kernel<TO, false, 1><<<grid, SK_THREADS, 0, s>>>(a);
+    } else {
+        const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
+        if (a.ln_colsum) gemm_skinny_kernel<TO, true, 2><<<grid, SK_THREADS, 0, s>>>(a);
+        else gemm_skinny_kernel<TO, false, 2><<<grid, SK_THREADS, 0, s>>>(a);
+    }
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;
         if (blocks > 1024) blocks = 1024;
@@ -166,7 +218,7 @@ int gemm_skinny_ksplit(int64_t k) { return (int)((k / 32 + SK_MAX_STEPS - 1) / S
 
 bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch) {
     if (in_dtype != MSSR_BF16 || batch != 1) return false;
-    if (a.m < 1 || a.m > 128 || a.k < 32 || a.k % 32 != 0) return false;
+    if (a.m < 1 || a.m > SK_MAX_M || (a.m + 31) / 32 > 65535 || a.k < 32 || a.k % 32 != 0) return false;
     if (a.a_cs != 1 || a.b_rs != 1) return false;                       // both operands k-contiguous
     if (a.a_rs % 8 != 0 || a.b_cs % 8 != 0 || !aligned(a.a, 16) || !aligned(a.b, 16)) return false;
     const int ks = gemm_skinny_ksplit(a.k);

@@ -415,7 +415,8 @@ def test_decoder_golden(ops, golden_modules):
 
 
 @pytest.mark.parametrize("M,N,K", [(80, 512, 512), (1, 512, 64), (16, 1536, 512), (128, 9606, 512), (80, 512, 9632),
-                                   (77, 130, 1024), (80, 1024, 2048)])
+                                   (77, 130, 1024), (80, 1024, 2048), (1280, 512, 512), (1360, 1024, 256),
+                                   (129, 48, 1024), (300, 100, 4096)])
 def test_gemm_skinny_path(ops, M, N, K):
     """The M <= 128 weight-streaming kernel (gemm_skinny.hip) against fp64 and against the general
     tiled kernel, including split-K (K > 1024) and every epilogue feature."""
@@ -455,7 +456,8 @@ def test_gemm_skinny_beta_accumulates(ops):
     assert_close(out, c0.double() + a.double() @ w.double().t(), 2e-5 * math.sqrt(512), "beta")
 
 
-@pytest.mark.parametrize("M,N,K", [(80, 1536, 512), (20, 512, 512), (80, 1024, 512), (33, 48, 256)])
+@pytest.mark.parametrize("M,N,K", [(80, 1536, 512), (20, 512, 512), (80, 1024, 512), (33, 48, 256), (1360, 768, 256),
+                                   (1280, 1536, 512)])
 def test_gemm_skinny_layernorm_prologue(ops, M, N, K):
     """LayerNorm folded into the product: raw rows x, gamma-scaled weights, column sums and a folded
     bias give LN(x) W^T + b and the row statistics, against fp64 LayerNorm -> Linear."""
