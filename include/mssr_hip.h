@@ -179,6 +179,36 @@ int mssr_embedding_bwd(const void* dout, const int64_t* ids, float* dweight, int
 int mssr_scale_add_pe(const void* x, const float* pe, void* out, int64_t rows, int d, int64_t batch,
                       int step, float scale, int dtype, void* stream);
 
+/* ------------------------------------------------------------- fused attention ------------
+ * ctx = dropout(softmax(mask(q k^T / sqrt(dh)))) v for short sequences, one kernel per direction.
+ * Replaces onmt/modules/multi_headed_attn.py:187-205 (query scaling, matmul, masked_fill(mask, -1e18),
+ * fp32 softmax, dropout, matmul) on the no-cache branch (:161-166) and its autograd backward.
+ * q/k/v are [B, L, H, dh] views (head h at column offset h*dh) addressed by batch and row strides in
+ * elements (multiples of 4), so the packed projection [B*L, 3d] is used in place; mask is uint8,
+ * nonzero = masked, row of (b, i) at mask + b*mask_bs + i*mask_qs (mask_qs = 0: key padding only).
+ * Limits: Lk <= 64, dh <= 64 (and Lq <= 64 backward), staged tiles within 64 KB of LDS --
+ * mssr_attention_fits() tells; larger shapes go through mssr_gemm + mssr_softmax_*.
+ * Dropout: keep(b,h,i,t) = hash(seed, ((b*H+h)*Lq + i)*64 + t) >= p_drop * 2^32, regenerated by the
+ * backward from the same seed. */
+typedef struct {
+    const void *q, *k, *v;
+    const uint8_t* mask;          /* may be NULL */
+    int B, H, Lq, Lk, dh;
+    int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, mask_bs, mask_qs;
+    float p_drop;                 /* 0 = no dropout */
+    uint64_t seed;
+    int dtype;
+} mssr_attn_desc;
+int mssr_attention_fits(int Lq, int Lk, int dh, int dtype, int backward);
+/* ctx row (b, i) at ctx + b*ctx_bs + i*ctx_ls, head h at column h*dh; probs (may be NULL) receives the
+ * probabilities BEFORE dropout as contiguous [B, H, Lq, Lk] (what the module returns, :223-227). */
+int mssr_attention_fwd(const mssr_attn_desc* desc, void* ctx, int64_t ctx_bs, int64_t ctx_ls, void* probs,
+                       void* stream);
+/* dq, dk, dv from dctx (same layout conventions); probabilities are recomputed from q and k. */
+int mssr_attention_bwd(const mssr_attn_desc* desc, const void* dctx, int64_t dc_bs, int64_t dc_ls, void* dq,
+                       int64_t dq_bs, int64_t dq_ls, void* dk, int64_t dk_bs, int64_t dk_ls, void* dv,
+                       int64_t dv_bs, int64_t dv_ls, void* stream);
+
 /* ------------------------------------------------- step-wise soft-decode engine -----------
  * Replaces the Python loop of the reference's differentiable decoding,
  * TrainTranslator.decode_batch_ori (onmt/train_and_translate.py:202-231) ->

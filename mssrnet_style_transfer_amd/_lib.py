@@ -55,6 +55,15 @@ class DecodePlan(Structure):
                                            "ds_self", "ds_ctx", "d_e", "dnf")])
 
 
+class AttnDesc(Structure):
+    """mssr_attn_desc (include/mssr_hip.h)."""
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("mask", c_void_p),
+                ("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("dh", c_int),
+                ("q_bs", c_int64), ("q_ls", c_int64), ("k_bs", c_int64), ("k_ls", c_int64),
+                ("v_bs", c_int64), ("v_ls", c_int64), ("mask_bs", c_int64), ("mask_qs", c_int64),
+                ("p_drop", c_float), ("seed", c_uint64), ("dtype", c_int)]
+
+
 class ProfRecord(Structure):
     """mssr_prof_record (include/mssr_hip.h)."""
     _fields_ = [("kernel", c_int), ("in_dtype", c_int), ("out_dtype", c_int), ("tile", c_int),
@@ -83,6 +92,9 @@ SIGNATURES = {
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
     "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),
+    "mssr_attention_fits": ([_I, _I, _I, _I, _I], c_int),
+    "mssr_attention_fwd": ([POINTER(AttnDesc), _P, _L, _L, _P, _P], c_int),
+    "mssr_attention_bwd": ([POINTER(AttnDesc), _P, _L, _L, _P, _L, _L, _P, _L, _L, _P, _L, _L, _P], c_int),
     "mssr_prof_start": ([_I], c_int),
     "mssr_prof_stop": ([], c_int),
     "mssr_prof_get": ([_I, POINTER(ProfRecord)], c_int),

@@ -595,10 +595,115 @@ def embed_pe(ids, weight, pe2d, step, s, pad_idx):
     return _EmbedPe.apply(ids, weight, pe2d, step, float(s), pad_idx)
 
 
-def attention(q, k, v, mask, p_drop, training):
+class second_order:
+    """Context manager: build graphs that can be differentiated twice (the WGAN-GP penalties,
+    onmt/trainer_wgan_wh.py:1247-1250,1315-1318).  Inside it the fused attention kernel and the encoder
+    engine, whose backward passes are single kernels / C calls, step aside for the compositions of
+    matmul / softmax / dropout ops above, every one of which has a differentiable backward."""
+
+    def __enter__(self):
+        self.prev = _state.get("second_order", False)
+        _state["second_order"] = True
+
+    def __exit__(self, *exc):
+        _state["second_order"] = self.prev
+
+
+def second_order_active():
+    return _state.get("second_order", False)
+
+
+def _head_view_ok(t):
+    """[B,H,L,dh] view of [B,L,H,dh]-like memory: unit feature stride, heads dh apart, 4-element aligned."""
+    dh = t.shape[-1]
+    return (t.stride(-1) == 1 and (t.shape[1] == 1 or t.stride(1) == dh) and t.stride(0) % 4 == 0
+            and t.stride(2) % 4 == 0 and t.data_ptr() % (4 * t.element_size()) == 0)
+
+
+def _as_head_view(t):
+    t = cast(t)
+    if _head_view_ok(t):
+        return t
+    return t.transpose(1, 2).contiguous().transpose(1, 2)
+
+
+def _attn_desc(q, k, v, mask, p_drop, seed):
+    d = L.AttnDesc()
+    B, H, Lq, dh = q.shape
+    d.q, d.k, d.v = q.data_ptr(), k.data_ptr(), v.data_ptr()
+    d.B, d.H, d.Lq, d.Lk, d.dh = B, H, Lq, k.shape[2], dh
+    d.q_bs, d.q_ls, d.k_bs, d.k_ls, d.v_bs, d.v_ls = (q.stride(0), q.stride(2), k.stride(0), k.stride(2), v.stride(0),
+                                                     v.stride(2))
+    if mask is not None:
+        d.mask, d.mask_bs = mask.data_ptr(), (mask.stride(0) if B > 1 else 0)
+        d.mask_qs = mask.stride(1) if mask.shape[1] > 1 else 0
+    d.p_drop, d.seed, d.dtype = p_drop, seed, L.dt(q)
+    return d
+
+
+class _FusedAttention(Function):
+    """softmax(mask(q k^T / sqrt(dh))) v in one kernel per direction (csrc/attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, mask, p_drop, want_probs):
+        qc, kc, vc = _as_head_view(q), _as_head_view(k), _as_head_view(v)
+        L.require_cuda(qc, kc, vc)
+        B, H, Lq, dh = qc.shape
+        Lk = kc.shape[2]
+        m = None
+        if mask is not None:
+            m = mask if mask.stride(-1) == 1 else mask.contiguous()
+            m = m.view(torch.uint8) if m.dtype == torch.bool else (m if m.dtype == torch.uint8 else
+                                                                  (m != 0).view(torch.uint8))
+            if m.dim() != 3 or m.shape[0] != B or m.shape[2] != Lk or m.shape[1] not in (1, Lq):
+                raise ValueError("mask shape %s does not fit scores [%d,%d,%d,%d]" % (tuple(mask.shape), B, H, Lq, Lk))
+        seed = next_seed() if p_drop > 0.0 else 0
+        out = torch.empty(B, Lq, H, dh, dtype=qc.dtype, device=qc.device)
+        probs = torch.empty(B, H, Lq, Lk, dtype=qc.dtype, device=qc.device) if want_probs else None
+        d = _attn_desc(qc, kc, vc, m, p_drop, seed)
+        L.check(L.load().mssr_attention_fwd(d, out.data_ptr(), Lq * H * dh, H * dh, L.ptr(probs), L.stream()),
+                "attention_fwd")
+        ctx.save_for_backward(qc, kc, vc, m)
+        ctx.p_drop, ctx.seed = p_drop, seed
+        ctx.in_dtypes = (q.dtype, k.dtype, v.dtype)
+        if probs is not None:
+            ctx.mark_non_differentiable(probs)
+        return out.permute(0, 2, 1, 3), probs
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dctx, _dprobs):
+        qc, kc, vc, m = ctx.saved_tensors
+        B, H, Lq, dh = qc.shape
+        Lk = kc.shape[2]
+        dc = cast(dctx).permute(0, 2, 1, 3)
+        if not dc.is_contiguous():
+            dc = dc.contiguous()
+        dq = torch.empty(B, Lq, H, dh, dtype=qc.dtype, device=qc.device)
+        dk = torch.empty(B, Lk, H, dh, dtype=qc.dtype, device=qc.device)
+        dv = torch.empty(B, Lk, H, dh, dtype=qc.dtype, device=qc.device)
+        d = _attn_desc(qc, kc, vc, m, ctx.p_drop, ctx.seed)
+        L.check(L.load().mssr_attention_bwd(d, dc.data_ptr(), Lq * H * dh, H * dh, dq.data_ptr(), Lq * H * dh, H * dh,
+                                            dk.data_ptr(), Lk * H * dh, H * dh, dv.data_ptr(), Lk * H * dh, H * dh,
+                                            L.stream()), "attention_bwd")
+        tq, tk, tv = ctx.in_dtypes
+        return (dq.permute(0, 2, 1, 3).to(tq), dk.permute(0, 2, 1, 3).to(tk), dv.permute(0, 2, 1, 3).to(tv), None, None,
+                None)
+
+
+def attention(q, k, v, mask, p_drop, training, want_probs=True):
     """softmax(mask(q k^T / sqrt(dh))) v on [B,H,L,dh] views; returns (context as a [B,H,Lq,dh]
-    view of [B,Lq,H,dh] memory, probabilities [B,H,Lq,Lk] before dropout) -- onmt/modules/multi_headed_attn.py:187-205."""
+    view of [B,Lq,H,dh] memory, probabilities [B,H,Lq,Lk] before dropout) -- onmt/modules/multi_headed_attn.py:187-205.
+    Short sequences run the fused kernel; inside ``second_order()`` or beyond its limits the same
+    arithmetic is composed from matmul / softmax / dropout."""
     dh = q.shape[-1]
+    p = float(p_drop) if training else 0.0
+    if not second_order_active():
+        cd = _state["dtype"]
+        code = L.F32 if cd == torch.float32 else L.BF16
+        needs_bwd = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+        if L.load().mssr_attention_fits(q.shape[2], k.shape[2], dh, code, int(needs_bwd)):
+            return _FusedAttention.apply(q, k, v, mask, p, want_probs)
     scores = matmul(q, k, tb=True)
     probs = softmax(scores, mask, 1.0 / math.sqrt(dh))
     pd = dropout(probs, p_drop, training)

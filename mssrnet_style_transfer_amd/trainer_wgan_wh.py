@@ -14,6 +14,7 @@ import torch
 import torch.nn.functional as F
 from torch.nn.utils import clip_grad_norm_
 
+from . import ops
 from .train_and_translate import decode_batch_ori, generator_probs
 from .utils.misc import sequence_mask
 
@@ -35,7 +36,8 @@ def penalize_gen_style_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10
     (torch.rand(B,1,1).type_as(real), trainer_wgan_wh.py:1238)."""
     alpha = torch.rand(real.size(0), 1, 1).to(real)
     inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
-    err = cal_disc_loss(d_model(inter, lengths), labels)
+    with ops.second_order():
+        err = cal_disc_loss(d_model(inter, lengths), labels)
     g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     if gp_norm_seq:
         g = g.contiguous().view(-1, g.size(-1))[sequence_mask(lengths).contiguous().view(-1)]
@@ -47,7 +49,8 @@ def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.
     x_len = real.size(1)
     alpha = torch.rand(real.size(0), 1, 1).to(real)
     inter = (alpha * real + (1 - alpha) * fake).transpose(0, 1).detach().requires_grad_(True)
-    err = cal_disc_loss(d_model(inter, lengths), labels)
+    with ops.second_order():
+        err = cal_disc_loss(d_model(inter, lengths), labels)
     g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     g = g.transpose(0, 1)
     if gp_norm_seq:

@@ -272,8 +272,11 @@ def run_mha(c, dtype=torch.float32):
 
 @pytest.mark.parametrize("name", ["self_pad", "self_causal", "cross", "nomask", "self_pad_d256", "cross_d512"])
 def test_mha_golden_fp32(ops, golden_ops, name):
+    """Composed path (ops.second_order(): what the WGAN-GP critics run): values, gradients through both
+    outputs and the double-backward probe against the reference's vectors."""
     c = golden_ops["mha_" + name]
-    m, ins, o, attn = run_mha(c)
+    with ops.second_order():
+        m, ins, o, attn = run_mha(c)
     assert_close(o, c["out"], TOL32, "out")
     assert_close(attn, c["attn"], TOL32, "attn")
     names = list(ins.keys()) + [n for n, _ in m.named_parameters()]
@@ -292,7 +295,8 @@ def test_mha_bf16(ops, golden_ops):
     try:
         for name in ("self_pad", "cross_d512"):
             c = golden_ops["mha_" + name]
-            m, ins, o, attn = run_mha(c)
+            with ops.second_order():
+                m, ins, o, attn = run_mha(c)
             assert o.dtype == torch.bfloat16
             assert_close(o.float(), c["out"], TOL16, "out bf16")
             assert_close(attn.float(), c["attn"], TOL16, "attn bf16")
@@ -305,6 +309,65 @@ def test_mha_bf16(ops, golden_ops):
             assert_grads(dict(zip(names, g)), c["g"], 4e-2, "g bf16", floor_rel=2e-2)
     finally:
         ops.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("name", ["self_pad", "self_causal", "cross", "nomask", "self_pad_d256", "cross_d512"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mha_fused_kernel(ops, golden_ops, name, dtype):
+    """The fused attention kernel (csrc/attention.hip, the default path) against the reference's vectors
+    (outputs, probabilities) and against the composed path's first-order gradients."""
+    c = golden_ops["mha_" + name]
+    tol, gtol = (TOL32, 2e-4) if dtype == torch.float32 else (TOL16, 4e-2)
+    ops.set_compute_dtype(dtype)
+    try:
+        m, ins, o, attn = run_mha(c)
+        assert o.grad_fn is not None and not attn.requires_grad          # fused: probabilities carry no graph
+        assert_close(o.float(), c["out"], tol, "out")
+        assert_close(attn.float(), c["attn"], tol, "attn")
+        tens = list(ins.values()) + list(m.parameters())
+        names = list(ins.keys()) + [n for n, _ in m.named_parameters()]
+        g = torch.autograd.grad((o.float() * dev(c["wo"])).sum(), tens)
+        with ops.second_order():
+            m2, ins2, o2, _ = run_mha(c)
+        g2 = torch.autograd.grad((o2.float() * dev(c["wo"])).sum(), list(ins2.values()) + list(m2.parameters()))
+        assert_grads(dict(zip(names, g)), dict(zip(names, g2)), gtol, "fused vs composed",
+                     floor_rel=1e-5 if dtype == torch.float32 else 2e-2)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+def test_fused_attention_dropout_and_limits(ops):
+    """Dropout inside the fused kernel: the backward regenerates the forward's mask (directional finite
+    difference under a fixed seed); shapes beyond the kernel's limits take the composed path."""
+    torch.manual_seed(0)
+    B, H, L, dh = 3, 4, 9, 16
+    q, k, v = (torch.randn(B, L, H * dh, device="cuda").view(B, L, H, dh).transpose(1, 2) for _ in range(3))
+    w = torch.randn(B, H, L, dh, device="cuda")
+    d = torch.randn_like(q)
+
+    def f(qq):
+        ops._state["seed_counter"] = 77
+        out, _ = ops.attention(qq, k, v, None, 0.4, True)
+        return out
+
+    qg = q.clone().requires_grad_(True)
+    out = f(qg)
+    (out * w).sum().backward()
+    with torch.no_grad():
+        assert torch.equal(f(q), out.detach())
+        assert float((f(q) - ops.attention(q, k, v, None, 0.4, False)[0]).abs().max()) > 1e-4
+        eps = 1e-2
+        fd = float(((f(q + eps * d) - f(q - eps * d)) * w).sum() / (2 * eps))
+    an = float((qg.grad * d).sum())
+    assert abs(an - fd) <= 2e-2 * max(abs(fd), 1e-3), (an, fd)
+    from mssrnet_style_transfer_amd import _lib
+    lib = _lib.load()
+    assert lib.mssr_attention_fits(17, 17, 64, _lib.BF16, 1) == 1
+    assert lib.mssr_attention_fits(130, 130, 64, _lib.BF16, 0) == 0
+    big = torch.randn(2, 2, 70, 16, device="cuda")
+    o_big, p_big = ops.attention(big, big, big, None, 0.0, False)          # composed path, same contract
+    ref = torch.softmax(big @ big.transpose(-1, -2) / 4.0, -1) @ big
+    assert_close(o_big, ref, 1e-4, "beyond the fused limits")
 
 
 def test_mha_cached(ops, golden_ops):
