@@ -209,6 +209,59 @@ int mssr_attention_bwd(const mssr_attn_desc* desc, const void* dctx, int64_t dc_
                        int64_t dq_bs, int64_t dq_ls, void* dk, int64_t dk_bs, int64_t dk_ls, void* dv,
                        int64_t dv_bs, int64_t dv_ls, void* stream);
 
+/* ------------------------------------------------------- encoder-stack engine -------------
+ * Replaces the Python layer loop of TransformerEncoder.forward (onmt/encoders/transformer.py:117-136)
+ * -> n_layers x TransformerEncoderLayer.forward (:37-52) -> final LayerNorm (:132), the same loop
+ * inside StyleGenerator2.forward (onmt/style_generator.py:40-47), and their autograd backward.
+ * The caller embeds the input (rows batch-first, R = B*L) into X[0] and owns every buffer.
+ * Weights in the compute dtype, nn.Linear layout [out,in] (w_*) and transposed (wt_*, backward);
+ * biases and LayerNorm parameters float.  `layers` is a HOST array. */
+typedef struct {
+    const void *w_qkv, *wt_qkv;   /* self_attn query|keys|values rows packed [3d,d]; wt [d,3d] */
+    const void *w_o, *wt_o;       /* self_attn.final_linear [d,d] */
+    const void *w_1, *wt_1;       /* feed_forward.w_1 [ff,d]; wt [d,ff] */
+    const void *w_2, *wt_2;       /* feed_forward.w_2 [d,ff]; wt [ff,d] */
+    const float *b_qkv, *b_o, *b_1, *b_2;
+    const float *ln1_g, *ln1_b;   /* layer.layer_norm */
+    const float *lnf_g, *lnf_b;   /* feed_forward.layer_norm */
+    /* fuse_ln (forward-only bf16 plans; see mssr_gemm_desc.ln_colsum): gamma-scaled weights, their row
+     * sums, W beta + b.  May be NULL when fuse_ln = 0. */
+    const void *wg_qkv, *wg_1;
+    const float *cs_qkv, *cs_1, *bf_qkv, *bf_1;
+} mssr_enc_layer;
+
+typedef struct {
+    int dtype, B, L, d, heads, ff, n_layers;
+    int save;                     /* 1: keep per-layer activations for mssr_encoder_bwd */
+    int training;                 /* 1: dropout active */
+    int fuse_ln;                  /* 1: LayerNorms folded into the projections (save = 0, bf16 only) */
+    float p_drop, p_attn;
+    uint64_t seed;
+    const mssr_enc_layer* layers; /* host array [n_layers] */
+    const float *lnF_g, *lnF_b;   /* encoder.layer_norm */
+    const uint8_t* mask;          /* [B, L] nonzero = padding key (may be NULL) */
+    void* X;                      /* [n_layers+1][R, d]: X[0] = input, X[l+1] = output of layer l */
+    void* out;                    /* [R, d] = LayerNorm(X[n_layers]) */
+    void* qkv;                    /* [Ls][R, 3d]   (Ls = save ? n_layers : 1) */
+    void* actD;                   /* [Ls][4][R, d]  n1 | ctx | h | n2 */
+    void* actF;                   /* [Ls][R, ff]    FFN inner activation */
+    float* stats;                 /* [2*n_layers+1][2][R] LayerNorm mean, rstd */
+    void* gemm_ws;                /* split-K scratch of mssr_gemm (may be NULL) */
+    int64_t gemm_ws_bytes;
+    /* backward only */
+    const void* dout;             /* [R, d] dL/d out */
+    void* dX;                     /* [R, d] on return: dL/d X[0] */
+    void* dqkv;                   /* [n_layers][R, 3d] */
+    void* dactD;                  /* [n_layers][4][R, d]  dn1 | d_o | dn2 | d_f2 (gradients of the outputs of
+                                   * layer_norm, final_linear, feed_forward.layer_norm, w_2) */
+    void* dactF;                  /* [n_layers][R, ff]    gradient of the w_1 output */
+    void* dctx;                   /* [R, d] scratch */
+} mssr_encoder_plan;
+int mssr_encoder_fwd(const mssr_encoder_plan* plan, void* stream);
+/* Leaves the gradient of every Linear output in the d* slabs; the caller contracts them with the saved
+ * activations into parameter gradients (one batched product per kind over all layers). */
+int mssr_encoder_bwd(const mssr_encoder_plan* plan, void* stream);
+
 /* ------------------------------------------------- step-wise soft-decode engine -----------
  * Replaces the Python loop of the reference's differentiable decoding,
  * TrainTranslator.decode_batch_ori (onmt/train_and_translate.py:202-231) ->

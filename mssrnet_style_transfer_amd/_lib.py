@@ -41,6 +41,23 @@ class DecLayer(Structure):
         "wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1")]
 
 
+class EncLayer(Structure):
+    """mssr_enc_layer (include/mssr_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in (
+        "w_qkv", "wt_qkv", "w_o", "wt_o", "w_1", "wt_1", "w_2", "wt_2", "b_qkv", "b_o", "b_1", "b_2",
+        "ln1_g", "ln1_b", "lnf_g", "lnf_b", "wg_qkv", "wg_1", "cs_qkv", "cs_1", "bf_qkv", "bf_1")]
+
+
+class EncoderPlan(Structure):
+    """mssr_encoder_plan (include/mssr_hip.h)."""
+    _fields_ = ([(n, c_int) for n in ("dtype", "B", "L", "d", "heads", "ff", "n_layers", "save", "training", "fuse_ln")]
+                + [("p_drop", c_float), ("p_attn", c_float), ("seed", c_uint64), ("layers", POINTER(EncLayer))]
+                + [(n, c_void_p) for n in ("lnF_g", "lnF_b", "mask", "X", "out", "qkv", "actD", "actF", "stats",
+                                           "gemm_ws")]
+                + [("gemm_ws_bytes", c_int64)]
+                + [(n, c_void_p) for n in ("dout", "dX", "dqkv", "dactD", "dactF", "dctx")])
+
+
 class DecodePlan(Structure):
     """mssr_decode_plan (include/mssr_hip.h)."""
     _fields_ = ([(n, c_int) for n in ("dtype", "B", "d", "heads", "ff", "n_layers", "V", "Vp", "Ls", "T", "save",
@@ -98,6 +115,8 @@ SIGNATURES = {
     "mssr_prof_start": ([_I], c_int),
     "mssr_prof_stop": ([], c_int),
     "mssr_prof_get": ([_I, POINTER(ProfRecord)], c_int),
+    "mssr_encoder_fwd": ([POINTER(EncoderPlan), _P], c_int),
+    "mssr_encoder_bwd": ([POINTER(EncoderPlan), _P], c_int),
     "mssr_decode_step_fwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_step_bwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_fwd": ([POINTER(DecodePlan), _P], c_int),

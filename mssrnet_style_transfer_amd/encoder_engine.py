@@ -1,0 +1,225 @@
+"""Host side of the encoder-stack engine (csrc/encoder.hip, include/mssr_hip.h).
+
+``run_stack(encoder, x, pad_mask)`` runs ``encoder.transformer`` (all TransformerEncoderLayers) and
+``encoder.layer_norm`` on already embedded rows x [B, L, d] as ONE autograd node: the layer loop of
+TransformerEncoder.forward (onmt/encoders/transformer.py:127-132) and of StyleGenerator2.forward
+(onmt/style_generator.py:40-47).  Forward and backward are one C call each; parameter gradients are
+contracted afterwards with one batched product per parameter kind over all layers.
+
+The node is differentiable once.  Graphs that are differentiated twice (the WGAN-GP penalties) are
+built under ``ops.second_order()``, where ``run_stack`` declines and the caller loops over the
+modules (whose ops are closed under differentiation).
+"""
+import ctypes
+
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from . import ops
+from .decode_engine import _bgemm_t, _bsum
+
+N_ENC_LAYER_PARAMS = 16
+(_WQ, _BQ, _WK, _BK, _WV, _BV, _WO, _BO, _W1, _B1, _W2, _B2, _LNFG, _LNFB, _LN1G, _LN1B) = range(N_ENC_LAYER_PARAMS)
+E_N1, E_CTX, E_H, E_N2 = range(4)
+EG_DN1, EG_DO, EG_DN2, EG_DF2 = range(4)
+
+
+def _layer_params(layer):
+    sa, ff = layer.self_attn, layer.feed_forward
+    return [sa.linear_query.weight, sa.linear_query.bias, sa.linear_keys.weight, sa.linear_keys.bias,
+            sa.linear_values.weight, sa.linear_values.bias, sa.final_linear.weight, sa.final_linear.bias,
+            ff.w_1.weight, ff.w_1.bias, ff.w_2.weight, ff.w_2.bias, ff.layer_norm.weight, ff.layer_norm.bias,
+            layer.layer_norm.weight, layer.layer_norm.bias]
+
+
+def encoder_params(enc):
+    """[lnF_g, lnF_b] + 16 parameters per encoder layer, in a fixed order."""
+    out = [enc.layer_norm.weight, enc.layer_norm.bias]
+    for layer in enc.transformer:
+        out += _layer_params(layer)
+    return out
+
+
+class _Pack:
+    """Encoder-stack weights as the engine wants them (compute dtype, packed, transposed, LN-folded)."""
+
+    def __init__(self, params, n_layers, cd):
+        lnFg, lnFb = params[:2]
+        lp = [params[2 + i * N_ENC_LAYER_PARAMS: 2 + (i + 1) * N_ENC_LAYER_PARAMS] for i in range(n_layers)]
+        NL = n_layers
+        d = lp[0][_WQ].shape[1]
+        ff = lp[0][_W1].shape[0]
+        self.NL, self.d, self.ff, self.cd = NL, d, ff, cd
+        with torch.no_grad():
+            def rows(idx):
+                return torch.cat([lp[l][i].detach() for l in range(NL) for i in idx], 0)
+
+            def w(idx, n_out, n_in):
+                t = rows(idx).to(cd).view(NL, n_out, n_in)
+                return t, t.transpose(1, 2).contiguous()
+
+            def f(idx, n):
+                return rows(idx).float().view(NL, n).contiguous()
+
+            self.w_qkv, self.wt_qkv = w([_WQ, _WK, _WV], 3 * d, d)
+            self.w_o, self.wt_o = w([_WO], d, d)
+            self.w_1, self.wt_1 = w([_W1], ff, d)
+            self.w_2, self.wt_2 = w([_W2], d, ff)
+            self.b_qkv, self.b_o, self.b_1, self.b_2 = f([_BQ, _BK, _BV], 3 * d), f([_BO], d), f([_B1], ff), f([_B2], d)
+            self.ln1_g, self.ln1_b, self.lnf_g, self.lnf_b = f([_LN1G], d), f([_LN1B], d), f([_LNFG], d), f([_LNFB], d)
+            self.lnF_g, self.lnF_b = lnFg.detach().float().contiguous(), lnFb.detach().float().contiguous()
+            names = ["w_qkv", "wt_qkv", "w_o", "wt_o", "w_1", "wt_1", "w_2", "wt_2", "b_qkv", "b_o", "b_1", "b_2",
+                     "ln1_g", "ln1_b", "lnf_g", "lnf_b"]
+            self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
+            if self.fuse_ln:
+                def fold(idx, n_out, g, b, bias):
+                    w32 = rows(idx).float().view(NL, n_out, d)
+                    wg = (w32 * g.unsqueeze(1)).to(cd).contiguous()
+                    return wg, wg.float().sum(-1).contiguous(), (torch.bmm(w32, b.unsqueeze(2)).squeeze(2) + bias).contiguous()
+
+                self.wg_qkv, self.cs_qkv, self.bf_qkv = fold([_WQ, _WK, _WV], 3 * d, self.ln1_g, self.ln1_b, self.b_qkv)
+                self.wg_1, self.cs_1, self.bf_1 = fold([_W1], ff, self.lnf_g, self.lnf_b, self.b_1)
+                names += ["wg_qkv", "wg_1", "cs_qkv", "cs_1", "bf_qkv", "bf_1"]
+        arr = (L.EncLayer * NL)()
+        for l in range(NL):
+            for name in names:
+                setattr(arr[l], name, getattr(self, name)[l].data_ptr())
+        self.layers = arr
+
+
+_pack_cache = {}
+
+
+def get_pack(enc, params):
+    cd = ops.compute_dtype()
+    ver = (cd, tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:3]))
+    hit = _pack_cache.get(id(enc))
+    if hit is not None and hit[0] == ver and hit[2]() is enc:
+        return hit[1]
+    import weakref
+    pack = _Pack(params, len(enc.transformer), cd)
+    _pack_cache[id(enc)] = (ver, pack, weakref.ref(enc))
+    return pack
+
+
+class _Spec:
+    __slots__ = ("pack", "B", "L", "heads", "training", "p_drop", "p_attn", "seed", "mask", "save")
+
+
+class _EncoderStack(Function):
+    @staticmethod
+    def forward(ctx, spec, x, *params):
+        pk = spec.pack
+        lib = L.load()
+        cd, dev = pk.cd, x.device
+        B, Ln, NL, d, ff = spec.B, spec.L, pk.NL, pk.d, pk.ff
+        R = B * Ln
+        Ls = NL if spec.save else 1
+        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        bufs = dict(X=e(NL + 1, R, d), out=e(R, d), qkv=e(Ls, R, 3 * d), actD=e(Ls, 4, R, d), actF=e(Ls, R, ff),
+                    stats=e(2 * NL + 1, 2, R, dtype=torch.float32))
+        bufs["X"][0].view(B, Ln, d).copy_(x.detach())
+        plan = L.EncoderPlan()
+        plan.dtype = L.F32 if cd == torch.float32 else L.BF16
+        plan.B, plan.L, plan.d, plan.heads, plan.ff, plan.n_layers = B, Ln, d, spec.heads, ff, NL
+        plan.save, plan.training = int(spec.save), int(spec.training)
+        plan.fuse_ln = int(pk.fuse_ln and not spec.save)
+        plan.p_drop, plan.p_attn, plan.seed = spec.p_drop, spec.p_attn, spec.seed
+        plan.layers = pk.layers
+        plan.lnF_g, plan.lnF_b = pk.lnF_g.data_ptr(), pk.lnF_b.data_ptr()
+        plan.mask = L.ptr(spec.mask)
+        for name, t in bufs.items():
+            setattr(plan, name, t.data_ptr())
+        ws = ops._workspace(dev)
+        plan.gemm_ws, plan.gemm_ws_bytes = ws.data_ptr(), ws.numel() * 4
+        L.check(lib.mssr_encoder_fwd(ctypes.byref(plan), L.stream()), "encoder_fwd")
+        out = bufs.pop("out")
+        if spec.save:
+            ctx.spec, ctx.plan, ctx.bufs = spec, plan, bufs
+            ctx.x_dtype = x.dtype
+        return out.view(B, Ln, d)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dout):
+        spec, plan, bufs = ctx.spec, ctx.plan, ctx.bufs
+        if bufs is None:
+            raise RuntimeError("encoder stack: backward called twice (activations were released)")
+        pk = spec.pack
+        lib = L.load()
+        cd, dev = pk.cd, dout.device
+        B, Ln, NL, d, ff = spec.B, spec.L, pk.NL, pk.d, pk.ff
+        R = B * Ln
+        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        doutc = dout.to(cd).contiguous().view(R, d)
+        g = dict(dX=e(R, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 4, R, d), dactF=e(NL, R, ff), dctx=e(R, d))
+        plan.dout = doutc.data_ptr()
+        for name, t in g.items():
+            setattr(plan, name, t.data_ptr())
+        L.check(lib.mssr_encoder_bwd(ctypes.byref(plan), L.stream()), "encoder_bwd")
+        actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
+        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, E_N1]), _bsum(dqkv)
+        gW_o, gb_o = _bgemm_t(dactD[:, EG_DO], actD[:, E_CTX]), _bsum(dactD[:, EG_DO])
+        gW_1, gb_1 = _bgemm_t(dactF, actD[:, E_N2]), _bsum(dactF)
+        gW_2, gb_2 = _bgemm_t(dactD[:, EG_DF2], actF), _bsum(dactD[:, EG_DF2])
+        stats = bufs["stats"]
+        parts = lib.mssr_layernorm_partial_rows(R)
+        ws = e(2 * parts * d, dtype=torch.float32)
+        scratch = e(R, d)
+        ln_g = e(2 * NL + 1, 2, d, dtype=torch.float32)
+
+        def ln_grad(idx, dy, x, gamma):
+            L.check(lib.mssr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[idx, 0].data_ptr(),
+                                           stats[idx, 1].data_ptr(), scratch.data_ptr(), ln_g[idx, 0].data_ptr(),
+                                           ln_g[idx, 1].data_ptr(), ws.data_ptr(), R, d, plan.dtype, L.stream()),
+                    "layernorm_bwd")
+
+        for l in range(NL):
+            ln_grad(2 * l, dactD[l, EG_DN1], X[l], pk.ln1_g[l])
+            ln_grad(2 * l + 1, dactD[l, EG_DN2], actD[l, E_H], pk.lnf_g[l])
+        ln_grad(2 * NL, doutc, X[NL], pk.lnF_g)
+        out = [None, g["dX"].view(B, Ln, d).to(ctx.x_dtype), ln_g[2 * NL, 0], ln_g[2 * NL, 1]]
+        for l in range(NL):
+            out += [gW_qkv[l, :d], gb_qkv[l, :d], gW_qkv[l, d:2 * d], gb_qkv[l, d:2 * d], gW_qkv[l, 2 * d:],
+                    gb_qkv[l, 2 * d:], gW_o[l], gb_o[l], gW_1[l], gb_1[l], gW_2[l], gb_2[l],
+                    ln_g[2 * l + 1, 0], ln_g[2 * l + 1, 1], ln_g[2 * l, 0], ln_g[2 * l, 1]]
+        ctx.bufs = ctx.plan = None
+        return tuple(out)
+
+
+def run_stack(enc, x, pad_mask):
+    """LayerNorm(layers(x)) for x [B, L, d] (any strides) and pad_mask Bool/uint8 [B, L] (True = padding key),
+    or None when the engine does not apply (second-order graph, shapes beyond the fused attention
+    kernel, unequal dropout rates): the caller then loops over the modules."""
+    if ops.second_order_active() or len(enc.transformer) == 0:
+        return None
+    layer0 = enc.transformer[0]
+    B, Ln, d = x.shape
+    heads = layer0.self_attn.head_count
+    ffn = layer0.feed_forward
+    p_drop = float(layer0.dropout.p)
+    if abs(float(ffn.dropout_1.p) - p_drop) > 1e-12 or abs(float(ffn.dropout_2.p) - p_drop) > 1e-12:
+        return None
+    cd = ops.compute_dtype()
+    code = L.F32 if cd == torch.float32 else L.BF16
+    params = encoder_params(enc)
+    needs = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in params))
+    if d % heads or d % 8 or ffn.w_1.weight.shape[0] % 8:
+        return None
+    if not L.load().mssr_attention_fits(Ln, Ln, d // heads, code, int(needs)):
+        return None
+    spec = _Spec()
+    spec.pack = get_pack(enc, params)
+    spec.B, spec.L, spec.heads = B, Ln, heads
+    spec.training = bool(layer0.training)
+    spec.p_drop, spec.p_attn = p_drop, float(layer0.self_attn.dropout.p)
+    spec.seed = ops.next_seed()
+    m = pad_mask
+    if m is not None:
+        m = m.contiguous()
+        m = m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)
+    spec.mask = m
+    spec.save = bool(needs)
+    return _EncoderStack.apply(spec, ops.cast(x), *params)

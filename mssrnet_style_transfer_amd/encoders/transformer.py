@@ -9,6 +9,7 @@ lengths)``), pre-norm layers, LayerNorm eps 1e-6.  ``StyleGenerator2`` reaches i
 import torch.nn as nn
 
 from .. import ops
+from ..encoder_engine import run_stack
 from ..modules.multi_headed_attn import MultiHeadedAttention
 from ..modules.position_ffn import PositionwiseFeedForward
 from ..utils.misc import sequence_mask
@@ -60,12 +61,15 @@ class TransformerEncoder(EncoderBase):
         """src: Long [L, B, 1] or float [L, B, V]; lengths Long [B]."""
         self._check_args(src, lengths)
         emb = self.embeddings(src)
-        out = emb.transpose(0, 1).contiguous()
-        mask = ~sequence_mask(lengths, max_len=src.size(0)).unsqueeze(1)
-        for layer in self.transformer:
-            out = layer(out, mask)
-        ln = self.layer_norm
-        out = ops.layer_norm(out, ln.weight, ln.bias, ln.eps)
+        pad = ~sequence_mask(lengths, max_len=src.size(0))                 # [B, L], True = padding
+        out = run_stack(self, emb.transpose(0, 1), pad)                    # all layers + final LN: one C call
+        if out is None:                                                    # second-order graphs, long sequences
+            out = emb.transpose(0, 1).contiguous()
+            mask = pad.unsqueeze(1)
+            for layer in self.transformer:
+                out = layer(out, mask)
+            ln = self.layer_norm
+            out = ops.layer_norm(out, ln.weight, ln.bias, ln.eps)
         return emb, out.transpose(0, 1).contiguous(), lengths
 
     def update_dropout(self, dropout, attention_dropout):

@@ -14,6 +14,7 @@ from torch.nn.init import xavier_uniform_
 
 from . import ops
 from .decoders.transformer import TransformerDecoder
+from .encoder_engine import run_stack
 from .encoders.transformer import TransformerEncoder
 from .modules.embeddings import Embeddings
 from .modules.util_class import Cast
@@ -108,12 +109,16 @@ class StyleGenerator2(nn.Module):
         emb = enc.embeddings(src)
         # the style token row is neither scaled by sqrt(d) nor position-encoded (quirk 10)
         cls_emb = self.style_cls(desired_style).to(emb.dtype)
-        out = torch.cat((cls_emb.unsqueeze(0), emb), 0).transpose(0, 1).contiguous()
-        mask = ~sequence_mask(src_lengths + 1, max_len=src.size(0) + 1).unsqueeze(1)
-        for layer in enc.transformer:
-            out = layer(out, mask)
-        ln = enc.layer_norm
-        out = ops.layer_norm(out, ln.weight, ln.bias, ln.eps)
+        x = torch.cat((cls_emb.unsqueeze(0), emb), 0).transpose(0, 1)
+        pad = ~sequence_mask(src_lengths + 1, max_len=src.size(0) + 1)
+        out = run_stack(enc, x, pad)
+        if out is None:
+            out = x.contiguous()
+            mask = pad.unsqueeze(1)
+            for layer in enc.transformer:
+                out = layer(out, mask)
+            ln = enc.layer_norm
+            out = ops.layer_norm(out, ln.weight, ln.bias, ln.eps)
         return out.transpose(0, 1).contiguous()[1:]
 
 
