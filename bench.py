@@ -58,6 +58,7 @@ def roofline(records, dtype):
         ach, peak, unit, bound = a["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
     else:
         ach, peak, unit, bound = a["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS[key], "TFLOP/s", "mfma"
+    # traffic: HBM bytes from rocprofv3 PMC counters need a separate profiler pass; not collected in-process
     return dict(bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 5), traffic=None,
                 kernel=name, launches_per_step=a["launches"], avg_launch_us=round(a["ms"] * 1e3 / a["launches"], 2),
                 algorithmic_bytes_per_launch=int(a["bytes"] / a["launches"]),
