@@ -65,6 +65,9 @@ class MSSRConfig:
     max_extra_dec_steps: int = 10             # trainer_wgan_wh.py:149
     dec_temperature: float = 1.0
     max_dec_steps: int = 40
+    # not a reference flag: batch the independent style-generator / encoder / decode calls of the generator
+    # phase (same weights, same source) into single calls; results equal up to summation order
+    batch_generator_phase: bool = True
 
     @property
     def d_cls(self):

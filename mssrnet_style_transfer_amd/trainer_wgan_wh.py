@@ -15,7 +15,8 @@ import torch.nn.functional as F
 from torch.nn.utils import clip_grad_norm_
 
 from . import ops
-from .train_and_translate import decode_batch_ori, generator_probs
+from .decode_engine import soft_decode
+from .train_and_translate import decode_batch_ori, fetch_dec_output_length, generator_probs
 from .utils.misc import sequence_mask
 
 
@@ -206,6 +207,43 @@ class Trainer:
         return dict(TR_gain=v[0], TF_gain=v[1], T_gp=v[2], T_cost=v[1] - v[0] + v[2], T_Wgap=v[0] - v[1],
                     SR_gain=v[3], SF_gain=v[4], S_gp=v[5], S_cost=v[4] - v[3] + v[5], S_Wgap=v[3] - v[4])
 
+    def _train_generator_batched(self, batch):
+        """train_generator with its independent pieces batched (cfg.batch_generator_phase): the reference
+        runs the style generator three times and encoder + soft decode twice on the SAME weights and source
+        (onmt/trainer_wgan_wh.py:898-968); here they are one style-generator call on 3B rows and one
+        encoder + decode on 2B rows (the self-style half only needs the first tgt_len steps), and the three
+        backward() calls become one backward of the summed objective.  Same losses and gradients up to
+        floating-point summation order (the golden test holds both variants to the same tolerance); with
+        dropout on, the masks differ as they would between any two runs."""
+        cfg = self.cfg
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        tgt_len, B = vocab_target.size(0), vocab_target.size(1)
+        desired = 1 - labels
+        desired_list = desired.tolist()
+        max_dec_steps = tgt_len + cfg.max_extra_dec_steps
+        rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1),
+                                             real_len.repeat(3))
+        rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
+        src2, len2 = real_src.repeat(1, 2, 1), real_len.repeat(2)
+        enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep, rep3], 1))
+        self.model.decoder.init_state(src2, mem, enc_state)
+        probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
+        probs, sprobs = probs_all[:, :B], probs_all[:tgt_len, B:]
+        seq_lens_list, _ = fetch_dec_output_length(probs, cfg)
+        seq_lens = torch.tensor(seq_lens_list, dtype=torch.long, device=real_len.device)
+        lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
+        gain_t = cal_disc_loss(self._call_text_discriminator(probs, lens), desired_list).mean()
+        with torch.no_grad():
+            acc = self.classifier(probs, lens).argmax(-1).eq(desired).float().mean()
+        gain_s = cal_disc_loss(self._call_style_discriminator(rep2.transpose(0, 1), real_len), desired_list).mean()
+        vl = self.vocab_loss_from_probs(sprobs, vocab_target.contiguous().view(-1), B)
+        total = vl - cfg.text_ap_scale * gain_t - cfg.style_ap_scale * gain_s
+        self._arm(self.style_generator, self.model)
+        total.backward()
+        self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
+        v = torch.stack([t.detach().float() for t in (gain_t, acc, gain_s, vl)]).tolist()
+        return dict(AT_gain=v[0], AT_acc=v[1], AS_gain=v[2], T_selfstyle_vloss=v[3])
+
     def train_generator(self, batch):
         cfg = self.cfg
         self.style_generator.train()
@@ -214,6 +252,8 @@ class Trainer:
         self.text_discriminator.eval()
         self.style_generator_optim.zero_grad()
         self.model_optim.zero_grad()
+        if cfg.ap_gen_self_style_text and cfg.batch_generator_phase:
+            return self._train_generator_batched(batch)
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
         tgt_len, B = vocab_target.size(0), vocab_target.size(1)
         desired = 1 - labels                                   # num_styles == 2 (train_and_translate.py:72-73)
