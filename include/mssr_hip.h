@@ -347,6 +347,12 @@ typedef struct {
                                    * dL/d mem V = sum_s pd_s (x) dctx_s */
     void* d_e;                    /* [T][B, d] gradient of the soft-embedding product */
     void* dnf;                    /* [T][B, d] */
+    /* greedy search (beam 1): onmt/translate/translator_wh.py:709-746 + onmt/translate/greedy_search.py:135-165.
+     * greedy = 1 (forward-only plans): the next step's input is the one-hot of the argmax token instead of
+     * the probabilities, and the token goes to ids[step][b] (int32).  Sentences are independent, so running
+     * finished ones on (instead of compacting the batch as the reference does) leaves the others unchanged. */
+    int32_t* ids;                 /* [T][B] or NULL */
+    int greedy;
 } mssr_decode_plan;
 /* One decode step: embeds in_all[step], runs the layers with the cache rows 0..step, writes
  * probs[step] and in_all[step+1]. */

@@ -69,7 +69,8 @@ class DecodePlan(Structure):
                                            "stats", "nf", "logits", "tmp", "gemm_ws")]
                 + [("gemm_ws_bytes", c_int64)]
                 + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dctx",
-                                           "ds_self", "ds_ctx", "d_e", "dnf")])
+                                           "ds_self", "ds_ctx", "d_e", "dnf", "ids")]
+                + [("greedy", c_int)])
 
 
 class AttnDesc(Structure):

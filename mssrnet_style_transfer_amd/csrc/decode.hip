@@ -221,24 +221,39 @@ __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict
 
 // probs = softmax(logits * inv_t): fp32 result (the user-visible [B,V] slab) + a copy in the
 // compute dtype into the next step's padded GEMM operand row.  One 256-thread block per row.
+// greedy: the next input is the one-hot of the row's argmax instead (lowest index on ties, as
+// torch.topk(1) / argmax) and the index goes to ids[row]: the greedy search of
+// onmt/translate/greedy_search.py:135-165 with beam 1.
 template <typename T, int NE>
 __global__ __launch_bounds__(256) void vocab_softmax_kernel(const T* __restrict__ logits, int64_t ldl,
                                                             float* __restrict__ probs, int64_t ldp,
-                                                            T* __restrict__ copy, int64_t ldc, int n, float inv_t) {
+                                                            T* __restrict__ copy, int64_t ldc, int n, float inv_t,
+                                                            int greedy, int* __restrict__ ids) {
     __shared__ float sm[4];
+    __shared__ int si[4];
     const int t = threadIdx.x, row = blockIdx.x;
     float v[NE];
     float mx = -INFINITY;
+    int mi = 0x7fffffff;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
         const int c = t + i * 256;
         v[i] = c < n ? to_f(logits[(int64_t)row * ldl + c]) * inv_t : -INFINITY;
-        mx = fmaxf(mx, v[i]);
+        if (v[i] > mx) { mx = v[i]; mi = c; }
     }
-    mx = wave_max(mx);
-    if ((t & 63) == 0) sm[t >> 6] = mx;
+    // (max, lowest index attaining it) over the wave, then over the 4 waves
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    if ((t & 63) == 0) { sm[t >> 6] = mx; si[t >> 6] = mi; }
     __syncthreads();
-    mx = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    mx = sm[0]; mi = si[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (sm[w] > mx || (sm[w] == mx && si[w] < mi)) { mx = sm[w]; mi = si[w]; }
     __syncthreads();
     float sum = 0.f;
 #pragma unroll
@@ -256,9 +271,10 @@ __global__ __launch_bounds__(256) void vocab_softmax_kernel(const T* __restrict_
         if (c < n) {
             const float p = v[i] * inv;
             probs[(int64_t)row * ldp + c] = p;
-            if (copy) copy[(int64_t)row * ldc + c] = from_f<T>(p);
+            if (copy) copy[(int64_t)row * ldc + c] = from_f<T>(greedy ? (c == mi ? 1.0f : 0.f) : p);
         }
     }
+    if (greedy && ids && t == 0) ids[row] = mi;
 }
 
 // One chunk of the batch (rows b0 .. b0+Bc of every [B, .] slab) on its own stream: sentences are
@@ -323,6 +339,7 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
                      p->nf && p->logits && p->tmp,
                  "%s: null buffer in plan", who);
     MSSR_REQUIRE(p->temperature > 0.f, "%s: temperature must be positive", who);
+    MSSR_REQUIRE(!p->greedy || (!p->save && p->ids), "%s: greedy decoding is forward-only and needs the ids buffer", who);
     if (p->fuse_ln) {
         MSSR_REQUIRE(p->dtype == MSSR_BF16 && p->d % 32 == 0 && p->d <= 2048,
                      "%s: fuse_ln needs bf16 and a model dim that is a multiple of 32, <= 2048", who);
@@ -488,7 +505,8 @@ static int step_fwd(const Ctx& c, int step) {
     const int ne = (p->V + 255) / 256;
 #define VS(T, NEc)                                                                                             \
     vocab_softmax_kernel<T, NEc><<<R, 256, 0, c.s>>>((const T*)G.logits(), p->Vp, probs, p->V, (T*)copy, p->Vp, \
-                                                     p->V, 1.0f / p->temperature)
+                                                     p->V, 1.0f / p->temperature, p->greedy,                    \
+                                                     p->ids ? p->ids + (int64_t)step * B + G.r0 : nullptr)
     if (c.dt == MSSR_F32) {
         if (ne <= 8) VS(float, 8); else if (ne <= 16) VS(float, 16); else if (ne <= 40) VS(float, 40); else VS(float, 64);
     } else {

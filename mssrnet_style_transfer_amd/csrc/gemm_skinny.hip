@@ -18,6 +18,7 @@
 // K > 2048 is split across blockIdx.z into fp32 slabs; a second tiny kernel reduces them and applies
 // the epilogue (deterministic, no atomics).
 #include "gemm_common.hpp"
+#include <stdlib.h>
 
 namespace mssr {
 
@@ -198,7 +199,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const GemmArgs 
 
 template <typename TO>
 static void skinny_launch(const GemmArgs& a, hipStream_t s) {
-    if (a.m <= 128) {
+    // 16x16 tiles (more blocks, 32 KB of loads each) while the row count is small; 32x32 tiles halve the
+    // L2 traffic once there are plenty of blocks anyway
+    static const int64_t f1_max_m = [] {
+        const char* e = getenv("MSSR_SKINNY_F1_MAXM");
+        return e ? (int64_t)atoll(e) : (int64_t)512;     // measured: bs160 decode 104.8 vs 107.9 ms/step with 32x32
+    }();
+    if (a.m <= f1_max_m) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
         if (a.ln_colsum) gemm_skinny_kernel<TO, true, 1><<<grid, SK_THREADS, 0, s>>>(a);
         else gemm_skinny_kernel<TO, false, 1><<<grid, SK_THREADS, 0, s>>>(a);

@@ -162,44 +162,50 @@ def _bsum(dy):
     return ops.gemm(ones, dy, False, torch.float32).squeeze(1)
 
 
+def _make_plan(spec, mem):
+    """Slabs + mssr_decode_plan for one decode over ``mem`` [B, Ls, d] (forward part)."""
+    pk = spec.pack
+    cd, dev = pk.cd, mem.device
+    B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
+    L.require_cuda(mem)
+    memc = ops.cast(mem).detach().contiguous().view(B * Ls, d)
+    # context keys|values of the memory bank for every layer in one product: [B*Ls, NL*2d]
+    mem_kv = ops.gemm(memc, pk.w_ckv, True, cd, bias=pk.b_ckv)
+    Ts = T if spec.save else 1
+    e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+    bufs = dict(
+        mem=memc, mem_kv=mem_kv,
+        in_all=torch.zeros(T + 1, B, Vp, dtype=cd, device=dev),
+        probs=e(T, B, V, dtype=torch.float32),
+        X=e(NL + 1, Ts * B, d), qkv=e(NL, T * B, 3 * d), actD=e(NL, 8, Ts * B, d), actF=e(NL, Ts * B, ff),
+        stats=e(3 * NL + 1, 2, Ts * B, dtype=torch.float32), nf=e(Ts * B, d), logits=e(B, Vp), tmp=e(B, d),
+        ws=ops._workspace(dev))
+    bufs["in_all"][0, :, spec.bos] = 1
+    plan = L.DecodePlan()
+    plan.dtype = L.F32 if cd == torch.float32 else L.BF16
+    plan.B, plan.d, plan.heads, plan.ff, plan.n_layers = B, d, spec.heads, ff, NL
+    plan.V, plan.Vp, plan.Ls, plan.T = V, Vp, Ls, T
+    plan.save, plan.training = int(spec.save), int(spec.training)
+    plan.n_chunks = max(1, min(8, int(os.environ.get("MSSR_DECODE_CHUNKS", "1")), B))
+    plan.p_drop, plan.p_attn, plan.temperature, plan.seed = spec.p_drop, spec.p_attn, spec.temperature, spec.seed
+    plan.layers = pk.layers
+    plan.fuse_ln = int(pk.fuse_ln and os.environ.get("MSSR_DECODE_FUSE_LN", "1") != "0")
+    for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b") + (
+            ("wg_gen", "cs_gen", "bf_gen") if pk.fuse_ln else ()):
+        setattr(plan, name, getattr(pk, name).data_ptr())
+    plan.pe = spec.pe.data_ptr()
+    plan.src_mask = spec.src_mask.data_ptr()
+    for name in ("mem_kv", "in_all", "probs", "X", "qkv", "actD", "actF", "stats", "nf", "logits", "tmp"):
+        setattr(plan, name, bufs[name].data_ptr())
+    plan.gemm_ws, plan.gemm_ws_bytes = bufs["ws"].data_ptr(), bufs["ws"].numel() * 4
+    return plan, bufs
+
+
 class _SoftDecode(Function):
     @staticmethod
     def forward(ctx, spec, mem, *params):
-        pk = spec.pack
         lib = L.load()
-        cd, dev = pk.cd, mem.device
-        B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
-        L.require_cuda(mem)
-        memc = ops.cast(mem).detach().contiguous().view(B * Ls, d)
-        # context keys|values of the memory bank for every layer in one product: [B*Ls, NL*2d]
-        mem_kv = ops.gemm(memc, pk.w_ckv, True, cd, bias=pk.b_ckv)
-        Ts = T if spec.save else 1
-        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
-        bufs = dict(
-            mem=memc, mem_kv=mem_kv,
-            in_all=torch.zeros(T + 1, B, Vp, dtype=cd, device=dev),
-            probs=e(T, B, V, dtype=torch.float32),
-            X=e(NL + 1, Ts * B, d), qkv=e(NL, T * B, 3 * d), actD=e(NL, 8, Ts * B, d), actF=e(NL, Ts * B, ff),
-            stats=e(3 * NL + 1, 2, Ts * B, dtype=torch.float32), nf=e(Ts * B, d), logits=e(B, Vp), tmp=e(B, d),
-            ws=ops._workspace(dev))
-        bufs["in_all"][0, :, spec.bos] = 1
-        plan = L.DecodePlan()
-        plan.dtype = L.F32 if cd == torch.float32 else L.BF16
-        plan.B, plan.d, plan.heads, plan.ff, plan.n_layers = B, d, spec.heads, ff, NL
-        plan.V, plan.Vp, plan.Ls, plan.T = V, Vp, Ls, T
-        plan.save, plan.training = int(spec.save), int(spec.training)
-        plan.n_chunks = max(1, min(8, int(os.environ.get("MSSR_DECODE_CHUNKS", "1")), B))
-        plan.p_drop, plan.p_attn, plan.temperature, plan.seed = spec.p_drop, spec.p_attn, spec.temperature, spec.seed
-        plan.layers = pk.layers
-        plan.fuse_ln = int(pk.fuse_ln and os.environ.get("MSSR_DECODE_FUSE_LN", "1") != "0")
-        for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b") + (
-                ("wg_gen", "cs_gen", "bf_gen") if pk.fuse_ln else ()):
-            setattr(plan, name, getattr(pk, name).data_ptr())
-        plan.pe = spec.pe.data_ptr()
-        plan.src_mask = spec.src_mask.data_ptr()
-        for name in ("mem_kv", "in_all", "probs", "X", "qkv", "actD", "actF", "stats", "nf", "logits", "tmp"):
-            setattr(plan, name, bufs[name].data_ptr())
-        plan.gemm_ws, plan.gemm_ws_bytes = bufs["ws"].data_ptr(), bufs["ws"].numel() * 4
+        plan, bufs = _make_plan(spec, mem)
         L.check(lib.mssr_decode_fwd(ctypes.byref(plan), L.stream()), "decode_fwd")
         probs = bufs.pop("probs")
         if spec.save:
@@ -306,16 +312,12 @@ class _SoftDecode(Function):
         return tuple(out)
 
 
-def soft_decode(model, cfg, memory_bank, src_lengths, steps):
-    """vocab_probs [steps, B, V] (float) of the step-wise soft decode of ``model`` over
-    ``memory_bank`` [Ls, B, d] (the bonded encoder states)."""
+def _make_spec(model, cfg, memory_bank, src_lengths, steps, params):
     dec = model.decoder
-    params = decoder_params(model)
-    pack = get_pack(model, params)
     Ls, B, d = memory_bank.shape
     layer0 = dec.transformer_layers[0]
     spec = _Spec()
-    spec.pack, spec.B, spec.Ls, spec.T = pack, B, Ls, int(steps)
+    spec.pack, spec.B, spec.Ls, spec.T = get_pack(model, params), B, Ls, int(steps)
     spec.heads = layer0.self_attn.head_count
     spec.training = bool(dec.training)
     spec.p_drop, spec.p_attn = float(layer0.drop.p), float(layer0.self_attn.dropout.p)
@@ -331,7 +333,42 @@ def soft_decode(model, cfg, memory_bank, src_lengths, steps):
     spec.pe = dec.embeddings.make_embedding[1].table()
     if spec.T > spec.pe.shape[0]:
         raise ValueError("decode engine: %d steps exceed the positional table" % spec.T)
+    return spec
+
+
+def soft_decode(model, cfg, memory_bank, src_lengths, steps):
+    """vocab_probs [steps, B, V] (float) of the step-wise soft decode of ``model`` over
+    ``memory_bank`` [Ls, B, d] (the bonded encoder states)."""
+    params = decoder_params(model)
+    spec = _make_spec(model, cfg, memory_bank, src_lengths, steps, params)
     needs = torch.is_grad_enabled() and (memory_bank.requires_grad or any(p.requires_grad for p in params))
     spec.save = bool(needs)
     mem = memory_bank.transpose(0, 1).contiguous()          # [B, Ls, d]
     return _SoftDecode.apply(spec, mem, *params)
+
+
+def greedy_decode_ids(model, cfg, memory_bank, src_lengths, max_length, check_every=4):
+    """Greedy search with beam 1 on the decode engine: token ids [steps, B] (int32; steps <= max_length,
+    the loop stops once every sentence has produced </s>) -- the step loop of
+    onmt/translate/translator_wh.py:709-746 with GreedySearch.advance (greedy_search.py:135-165).
+    The reference drops finished sentences from the batch (update_finished + map_state(index_select),
+    translator_wh.py:744-746); sentences are independent, so here they simply run on and the caller
+    cuts each one at its first </s>."""
+    lib = L.load()
+    params = decoder_params(model)
+    with torch.no_grad():
+        spec = _make_spec(model, cfg, memory_bank, src_lengths, max_length, params)
+        spec.training, spec.save, spec.temperature = False, False, 1.0
+        plan, bufs = _make_plan(spec, memory_bank.transpose(0, 1).contiguous())
+        ids = torch.zeros(spec.T, spec.B, dtype=torch.int32, device=memory_bank.device)
+        plan.ids, plan.greedy = ids.data_ptr(), 1
+        done = torch.zeros(spec.B, dtype=torch.bool, device=memory_bank.device)
+        steps = 0
+        for step in range(spec.T):
+            L.check(lib.mssr_decode_step_fwd(ctypes.byref(plan), step, L.stream()), "decode_step_fwd")
+            steps = step + 1
+            if steps % check_every == 0 or steps == spec.T:
+                done |= (ids[steps - check_every if steps >= check_every else 0:steps] == cfg.eos_idx).any(0)
+                if bool(done.all()):                      # one host sync every `check_every` steps
+                    break
+    return ids[:steps]
