@@ -151,3 +151,19 @@ def test_engine_bf16_readme_shapes(ops):
         assert cos(ge[k], gm[k]) > 0.98, (k, cos(ge[k], gm[k]))
         ratio = float(ge[k].norm() / gm[k].norm())
         assert 0.9 < ratio < 1.1, (k, ratio)
+
+
+def test_engine_long_sequences_fp32(ops):
+    """More than 64 keys (config 5 territory: the step attention kernels loop over key blocks of 64, the
+    encoder side takes the composed attention path): engine vs modular, values and gradients."""
+    cfg = MSSRConfig.small()
+    B, Ls, steps = 3, 70, 67
+    model, src, lens, mem = setup(cfg, B, Ls, seed=6)
+    model.train()
+    w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
+    pe, ge_mem, ge, le, ie = run("decode_batch_ori", model, cfg, src, lens, mem, steps, w)
+    pm, gm_mem, gm, lm, im = run("decode_batch_modular", model, cfg, src, lens, mem, steps, w)
+    assert_close(pe, pm, 1e-4, "probs")
+    assert_close(ge_mem, gm_mem, 5e-4, "d memory_bank")
+    dec_keys = [k for k in gm if k.startswith("decoder.") or k.startswith("generator.")]
+    assert_grads({k: ge[k] for k in dec_keys}, {k: gm[k] for k in dec_keys}, 5e-4, "decoder")
