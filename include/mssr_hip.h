@@ -115,9 +115,10 @@ int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
 /* Launch timing for the benchmark's roofline (no reference counterpart): between mssr_prof_start
  * and mssr_prof_stop every mssr_gemm launch -- direct or from inside the decode engine -- is
  * bracketed by HIP events on the stream it is enqueued on.  kernel: 0 = gemm_kernel (tile = 32/64),
- * 1 = gemm_skinny_kernel (tile = number of split-K slabs).  Not thread-safe; host-side only. */
+ * 1 = gemm_skinny_kernel (tile = 16/32 output tile edge, ksplit = split-K slabs, ln = LayerNorm prologue).
+ * Host-side only. */
 typedef struct {
-    int kernel, in_dtype, out_dtype, tile;
+    int kernel, in_dtype, out_dtype, tile, ksplit, ln;
     int64_t batch, m, n, k;
     float ms;
 } mssr_prof_record;

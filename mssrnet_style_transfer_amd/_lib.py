@@ -84,7 +84,7 @@ class AttnDesc(Structure):
 
 class ProfRecord(Structure):
     """mssr_prof_record (include/mssr_hip.h)."""
-    _fields_ = [("kernel", c_int), ("in_dtype", c_int), ("out_dtype", c_int), ("tile", c_int),
+    _fields_ = [("kernel", c_int), ("in_dtype", c_int), ("out_dtype", c_int), ("tile", c_int), ("ksplit", c_int), ("ln", c_int),
                 ("batch", c_int64), ("m", c_int64), ("n", c_int64), ("k", c_int64), ("ms", c_float)]
 
 

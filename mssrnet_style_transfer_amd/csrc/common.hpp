@@ -13,7 +13,7 @@ void set_error(const char* fmt, ...);
 // bench instrumentation (core.hip): HIP events around a launch when mssr_prof_start() is active
 int prof_begin(hipStream_t s);
 void prof_end(int i, hipStream_t s, int kernel, int in_dt, int out_dt, int tile, int64_t batch, int64_t m, int64_t n,
-              int64_t k);
+              int64_t k, int ksplit = 1, int ln = 0);
 
 #define MSSR_REQUIRE(cond, ...)                 \
     do {                                        \

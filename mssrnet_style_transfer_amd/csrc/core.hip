@@ -33,13 +33,13 @@ int prof_begin(hipStream_t s) {
     return i;
 }
 void prof_end(int i, hipStream_t s, int kernel, int in_dt, int out_dt, int tile, int64_t batch, int64_t m, int64_t n,
-              int64_t k) {
+              int64_t k, int ksplit, int ln) {
     if (i < 0) return;
     ProfState& P = g_prof;
     (void)hipEventRecord(P.ev[2 * i + 1], s);
     mssr_prof_record& r = P.rec[i];
     r.kernel = kernel; r.in_dtype = in_dt; r.out_dtype = out_dt; r.tile = tile;
-    r.batch = batch; r.m = m; r.n = n; r.k = k; r.ms = -1.f;
+    r.batch = batch; r.m = m; r.n = n; r.k = k; r.ms = -1.f; r.ksplit = ksplit; r.ln = ln;
 }
 }  // namespace mssr
 

@@ -51,5 +51,6 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float acc, int
 bool gemm_skinny_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
 bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch);
 int gemm_skinny_ksplit(int64_t k);
+int gemm_skinny_tile(int64_t m);     // 16 or 32: output tile edge the K-split kernel uses for m rows
 
 }  // namespace mssr

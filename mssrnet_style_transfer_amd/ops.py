@@ -163,7 +163,8 @@ def stop_profile():
         isz, osz = (2 if r.in_dtype == L.BF16 else 4), (2 if r.out_dtype == L.BF16 else 4)
         tin, tout = ("bf16" if isz == 2 else "f32"), ("bf16" if osz == 2 else "f32")
         if r.kernel == 1:
-            name = "gemm_skinny_kernel<%d,%s>%s" % ((r.m + 15) // 16, tout, "+splitK" if r.tile > 1 else "")
+            name = "gemm_skinny_kernel<%s,%s,%d>%s" % (tout, "LN" if r.ln else "noLN", r.tile // 16,
+                                                      "+splitK" if r.ksplit > 1 else "")
         else:
             name = "gemm_kernel<%s,%s,%d>" % (tin, tout, r.tile)
         out.append(dict(kernel=name, in_dtype=tin, shape=(r.batch, r.m, r.n, r.k), ms=r.ms,
