@@ -248,6 +248,10 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
                  gemm_skinny_ksplit(d->k), d->ln_colsum ? 1 : 0);
         MSSR_LAUNCH_OK("gemm(skinny)");
     }
+    if (!d->no_skinny && gemm_tn_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+        prof_end(pi, s, 2, d->in_dtype, d->out_dtype, 64, batch, d->m, d->n, d->k);
+        MSSR_LAUNCH_OK("gemm(tn)");
+    }
     if (d->ln_colsum) {
         set_error("gemm: the LayerNorm prologue needs the K-split kernel (bf16, m <= 8192, k <= 2048, k %% 32 == 0, "
                   "k-contiguous 16-byte aligned operands)");

@@ -157,9 +157,24 @@ def _bgemm_t(dy, x):
 
 
 def _bsum(dy):
-    """column sums of dy [NL, R, n] (bias gradients) as a product with a row of ones -> float [NL, n]."""
-    ones = torch.ones(1, 1, dy.shape[-2], dtype=dy.dtype, device=dy.device).expand(dy.shape[0], 1, dy.shape[-2])
-    return ops.gemm(ones, dy, False, torch.float32).squeeze(1)
+    """column sums of dy [NL, R, n] (bias gradients of all layers) -> float [NL, n]; one mssr_colsum per layer."""
+    lib = L.load()
+    NL, R, n = dy.shape
+    if dy.stride(-1) != 1 or dy.stride(-2) != n:
+        dy = dy.contiguous()
+    out = torch.empty(NL, n, dtype=torch.float32, device=dy.device)
+    code, st = L.dt(dy), L.stream()
+    for l in range(NL):
+        L.check(lib.mssr_colsum(dy[l].data_ptr(), out[l].data_ptr(), R, n, n, 0, code, st), "colsum")
+    return out
+
+
+def _colsum(x):
+    """float column sums of a [rows, n] matrix (row stride allowed)."""
+    out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
+    L.check(L.load().mssr_colsum(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], x.stride(0), 0, L.dt(x),
+                                 L.stream()), "colsum")
+    return out
 
 
 def _make_plan(spec, mem):
@@ -272,7 +287,7 @@ class _SoftDecode(Function):
                          out=dmem_kv[:, :, l, which].permute(0, 2, 1, 3))
         dmem_kv = dmem_kv.view(B * Ls, NL * 2 * d)
         gW_ckv = _bgemm_t(dmem_kv, bufs["mem"]).view(NL, 2 * d, d)
-        gb_ckv = ops.gemm(torch.ones(1, B * Ls, dtype=cd, device=dev), dmem_kv, False, torch.float32).view(NL, 2 * d)
+        gb_ckv = _colsum(dmem_kv).view(NL, 2 * d)
         g_mem = None
         if ctx.needs_input_grad[1]:
             shape, dtype = ctx.mem_meta
@@ -297,7 +312,7 @@ class _SoftDecode(Function):
         # generator and (soft) embedding table
         dlg = g["dlogits"][:, :V]
         gW_gen = _bgemm_t(dlg, bufs["nf"])
-        gb_gen = ops.gemm(torch.ones(1, R, dtype=cd, device=dev), dlg, False, torch.float32).view(V)
+        gb_gen = _colsum(dlg)
         gE = _bgemm_t(bufs["in_all"][:T].view(R, Vp)[:, :V], g["d_e"])
 
         out = [None, g_mem, gE, ln_g[3 * NL, 0], ln_g[3 * NL, 1], gW_gen, gb_gen]

@@ -542,3 +542,31 @@ def test_gemm_skinny_layernorm_prologue(ops, M, N, K):
     assert_close(ro, 1.0 / (var.squeeze(1) + 1e-6).sqrt(), 1e-4, "rstd")
     with pytest.raises(RuntimeError):
         ops.gemm(x.cuda(), wg.cuda(), True, torch.bfloat16, bias=bias, ln=(colsum, mo, ro, 1e-6), no_skinny=True)
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(512, 512, 1280, 1), (1536, 512, 2240, 3), (130, 70, 100, 1), (9606, 256, 512, 1),
+                                         (64, 64, 64, 2), (48, 1024, 333, 1)])
+def test_gemm_tn_weight_gradient_kernel(ops, M, N, K, batch):
+    """dW = dY^T X with both operands k-major (gemm_tn.hip: LDS tiles read back through
+    ds_read_b64_tr_b16) against fp64, fp32 and bf16 outputs, beta accumulation, batched over layers,
+    ragged edges and unaligned leading dimensions."""
+    torch.manual_seed(M + N + K)
+    dy = torch.randn(batch, K, M).bfloat16().cuda()
+    x = torch.randn(batch, K, N).bfloat16().cuda()
+    ref = dy.double().transpose(1, 2) @ x.double()
+    from mssrnet_style_transfer_amd import _lib
+    ops.start_profile()
+    out = ops.gemm(dy.transpose(1, 2), x, False, torch.float32)
+    rec = ops.stop_profile()
+    assert rec[0]["kernel"].startswith("gemm_tn_kernel"), rec[0]["kernel"]
+    assert_close(out, ref, 2e-5 * math.sqrt(K), "tn f32")
+    out16 = ops.gemm(dy.transpose(1, 2), x, False, torch.bfloat16)
+    assert_close(out16.float(), ref, 1e-2, "tn bf16")
+    acc = torch.randn(batch, M, N, device="cuda")
+    want = acc.double() * 0.5 + 2.0 * ref
+    ops.gemm(dy.transpose(1, 2), x, False, torch.float32, out=acc, alpha=2.0, beta=0.5)
+    assert_close(acc, want, 3e-5 * math.sqrt(K), "tn alpha/beta")
+    if batch == 1:          # column slices: leading dimensions that are not multiples of 8, unaligned bases
+        dys, xs = dy[0][:, 3:M - 2], x[0][:, 1:N - 4]
+        o = ops.gemm(dys.t(), xs, False, torch.float32)
+        assert_close(o, ref[0][3:M - 2, 1:N - 4], 2e-5 * math.sqrt(K), "tn sliced")
