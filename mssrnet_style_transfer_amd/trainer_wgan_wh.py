@@ -69,8 +69,10 @@ class Trainer:
         self.classifier = nets["teacher"]
         self.classifier.eval()
         self.grad_sync = grad_sync
+        on_gpu = next(self.model.parameters()).is_cuda
+        # torch's multi-tensor fused Adam: one kernel per dtype group instead of ~10 foreach passes
         adam = lambda m: torch.optim.Adam(m.parameters(), lr=cfg.learning_rate,  # noqa: E731
-                                          betas=(cfg.adam_beta1, cfg.adam_beta2))
+                                          betas=(cfg.adam_beta1, cfg.adam_beta2), fused=on_gpu)
         self.style_generator_optim = adam(self.style_generator)
         self.style_discriminator_optim = adam(self.style_discriminator)
         self.text_discriminator_optim = adam(self.text_discriminator)
