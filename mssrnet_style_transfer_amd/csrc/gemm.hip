@@ -244,7 +244,7 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     const int pi = prof_begin(s);
     if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {
-        prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_tile(d->m), batch, d->m, d->n, d->k,
+        prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_tile(d->m, d->n, d->k), batch, d->m, d->n, d->k,
                  gemm_skinny_ksplit(d->k), d->ln_colsum ? 1 : 0);
         MSSR_LAUNCH_OK("gemm(skinny)");
     }

@@ -53,6 +53,6 @@ bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch);
 // returns true when the k-major ("TN", weight-gradient) kernel took the problem (gemm_tn.hip)
 bool gemm_tn_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
 int gemm_skinny_ksplit(int64_t k);
-int gemm_skinny_tile(int64_t m);     // 16 or 32: output tile edge the K-split kernel uses for m rows
+int gemm_skinny_tile(int64_t m, int64_t n, int64_t k);     // 16 or 32: output tile edge the K-split kernel uses
 
 }  // namespace mssr

@@ -200,17 +200,25 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const GemmArgs 
 // 16x16 tiles (more blocks, 32 KB of loads each) while the row count is small; 32x32 tiles halve the
 // L2 traffic once there are plenty of blocks anyway (measured: bs160 decode 104.8 ms/step with 16x16
 // vs 107.9 with 32x32; M = 1280 projections 11.6 us with 32x32 vs 14.2 with 16x16)
-int gemm_skinny_tile(int64_t m) {
+int gemm_skinny_tile(int64_t m, int64_t n, int64_t k) {
     static const int64_t f1_max_m = [] {
         const char* e = getenv("MSSR_SKINNY_F1_MAXM");
         return e ? (int64_t)atoll(e) : (int64_t)512;
     }();
-    return m <= f1_max_m ? 16 : 32;
+    static const int64_t f1_max_blocks = [] {
+        const char* e = getenv("MSSR_SKINNY_F1_MAXBLOCKS");
+        return e ? (int64_t)atoll(e) : (int64_t)2048;
+    }();
+    if (m <= 16) return 16;
+    // vocabulary-sized products (generator, soft embedding): thousands of 16x16 blocks re-read the operands
+    // through L2; 32x32 tiles halve that traffic
+    const int64_t blocks16 = ((m + 15) / 16) * ((n + 15) / 16) * gemm_skinny_ksplit(k);
+    return (m <= f1_max_m && blocks16 <= f1_max_blocks) ? 16 : 32;
 }
 
 template <typename TO>
 static void skinny_launch(const GemmArgs& a, hipStream_t s) {
-    if (gemm_skinny_tile(a.m) == 16) {
+    if (gemm_skinny_tile(a.m, a.n, a.k) == 16) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
         if (a.ln_colsum) gemm_skinny_kernel<TO, true, 1><<<grid, SK_THREADS, 0, s>>>(a);
         else gemm_skinny_kernel<TO, false, 1><<<grid, SK_THREADS, 0, s>>>(a);

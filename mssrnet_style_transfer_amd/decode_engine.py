@@ -132,7 +132,8 @@ def get_pack(model, params):
     """The packed weights of ``model``'s decoder, rebuilt when any parameter changed in place."""
     cd = ops.compute_dtype()
     key = id(model)
-    ver = (cd, tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:2]))
+    ver = (cd, tuple(p._version for p in params), sum(ops.param_epoch(p) for p in params),
+           tuple(p.data_ptr() for p in params[:2]))
     hit = _pack_cache.get(key)
     if hit is not None and hit[0] == ver:
         return hit[1]

@@ -94,7 +94,8 @@ _pack_cache = {}
 
 def get_pack(enc, params):
     cd = ops.compute_dtype()
-    ver = (cd, tuple(p._version for p in params), tuple(p.data_ptr() for p in params[:3]))
+    ver = (cd, tuple(p._version for p in params), sum(ops.param_epoch(p) for p in params),
+           tuple(p.data_ptr() for p in params[:3]))
     hit = _pack_cache.get(id(enc))
     if hit is not None and hit[0] == ver and hit[2]() is enc:
         return hit[1]

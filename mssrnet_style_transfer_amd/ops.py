@@ -38,6 +38,22 @@ def next_seed():
 
 
 _cast_cache = {}
+_param_epoch = {}
+
+
+def params_changed(*modules):
+    """Tell the weight caches (bf16 shadows here, the engines' packed weights) that the parameters of
+    ``modules`` were updated.  In-place updates that bump ``Parameter._version`` (torch's default / foreach
+    optimizers, ``load_state_dict``, ``p.add_``) are seen without this call; torch's FUSED optimizers write
+    through ``torch._fused_adam_`` and leave ``_version`` untouched, so a trainer that uses them must call
+    this after ``optimizer.step()`` (trainer_wgan_wh.Trainer does)."""
+    for m in modules:
+        for p in m.parameters():
+            _param_epoch[id(p)] = _param_epoch.get(id(p), 0) + 1
+
+
+def param_epoch(p):
+    return _param_epoch.get(id(p), 0)
 
 
 def cast(t):
@@ -48,10 +64,11 @@ def cast(t):
     if isinstance(t, torch.nn.Parameter):
         key = id(t)
         hit = _cast_cache.get(key)
-        if hit is not None and hit[0]() is t and hit[1] == t._version and hit[2] == t.data_ptr():
+        ver = (t._version, _param_epoch.get(key, 0))
+        if hit is not None and hit[0]() is t and hit[1] == ver and hit[2] == t.data_ptr():
             return hit[3]
         c = t.detach().to(cd)
-        _cast_cache[key] = (weakref.ref(t), t._version, t.data_ptr(), c)
+        _cast_cache[key] = (weakref.ref(t), ver, t.data_ptr(), c)
         return c
     return t.detach().to(cd) if not torch.is_grad_enabled() else t.to(cd)
 

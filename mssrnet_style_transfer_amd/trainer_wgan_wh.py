@@ -161,6 +161,7 @@ class Trainer:
                 clip_grad_norm_(m.parameters(), self.cfg.max_grad_norm)
         for o in optims:
             o.step()
+        ops.params_changed(*modules)        # fused optimizers do not bump Parameter._version
 
     # ------------------------------------------------------------------ phases
     def train_discriminator(self, batch):

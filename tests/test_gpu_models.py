@@ -238,3 +238,10 @@ def test_long_sequence_stress_phases_bf16(ops):
                 assert p.grad is None or torch.isfinite(p.grad).all(), n
     finally:
         ops.set_compute_dtype(torch.float32)
+
+
+def test_two_consecutive_steps_follow_the_oracle(ops):
+    """D phase then G phase with the optimizer steps in between (what smoke() runs): the weight caches (bf16
+    shadows, packed engine weights) must follow the fused-Adam updates, which do not bump Parameter._version."""
+    import __graft_entry__ as g
+    g.smoke()
