@@ -7,9 +7,9 @@ all_reduce(SUM), then divide by the number of ranks.  This module implements exa
 semantics -- reduced grad = (sum over ranks) / world -- once per optimizer step:
 
 * ``arm(module)`` before the LAST backward that touches ``module``: per-parameter
-  post-accumulate hooks copy each finished gradient into its flat bucket and launch the
-  bucket's all-reduce on a side stream as soon as the bucket is full, overlapping the rest
-  of that backward;
+  post-accumulate hooks count finished gradients; when a bucket's last gradient lands the bucket
+  is gathered into its flat buffer (one multi-tensor copy) and its all-reduce launched on a side
+  stream, overlapping the rest of that backward;
 * ``__call__(modules)`` after the last backward: reduces whatever was not armed / not
   flushed, waits for the side stream, divides by world and scatters back into ``.grad``.
 
@@ -53,8 +53,12 @@ class GradSync:
         plan = []
         for ps in buckets:
             n = sum(p.numel() for p in ps)
-            plan.append(dict(params=ps, flat=torch.zeros(n, dtype=torch.float32, device=ps[0].device),
-                             ready=0, launched=False, index={id(p): i for i, p in enumerate(ps)}))
+            flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+            views, off = [], 0
+            for p in ps:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            plan.append(dict(params=ps, flat=flat, views=views, ready=0, launched=False))
         self._plans[id(module)] = plan
         return plan
 
@@ -65,16 +69,15 @@ class GradSync:
             self._stream = torch.cuda.Stream(device=device)
         return self._stream
 
-    def _fill(self, b, only=None):
-        off = 0
-        for p in b["params"]:
-            n = p.numel()
-            if only is None or p is only:
-                if p.grad is None:
-                    b["flat"][off:off + n].zero_()
-                else:
-                    b["flat"][off:off + n].copy_(p.grad.reshape(-1))
-            off += n
+    def _fill(self, b):
+        """Gradients of the bucket's parameters -> its flat buffer: ONE multi-tensor copy (two kernels per
+        bucket instead of two per parameter); parameters without a gradient contribute zeros."""
+        dst = [v for v, p in zip(b["views"], b["params"]) if p.grad is not None]
+        src = [p.grad for p in b["params"] if p.grad is not None]
+        if len(dst) < len(b["params"]):
+            b["flat"].zero_()
+        if dst:
+            torch._foreach_copy_(dst, src)
 
     def _launch(self, b):
         if self.world <= 1:
@@ -101,9 +104,9 @@ class GradSync:
             b["ready"], b["launched"] = 0, False
             for p in b["params"]:
                 def hook(param, b=b):
-                    self._fill(b, only=param)
                     b["ready"] += 1
                     if b["ready"] == len(b["params"]) and not b["launched"]:
+                        self._fill(b)
                         self._launch(b)
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
 
@@ -125,15 +128,11 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self._stream)
         inv = 1.0 / self.world
         for b, _ in self._pending:
-            off = 0
-            for p in b["params"]:
-                n = p.numel()
-                g = b["flat"][off:off + n].view_as(p)
+            b["flat"].mul_(inv)
+            for v, p in zip(b["views"], b["params"]):
                 if p.grad is None:
-                    p.grad = (g * inv).to(p.dtype)
-                else:
-                    p.grad.copy_(g).mul_(inv)
-                off += n
+                    p.grad = v.clone().to(p.dtype)
+            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
             b["ready"], b["launched"] = 0, False
         self._pending = []
 
