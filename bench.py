@@ -8,7 +8,13 @@ normaliser, onmt/trainer_wgan_wh.py:389-391).  N > 1: one process per GPU under
 torch.distributed.run, batch-sharded (bs80 per GPU, weak scaling) with bucketed RCCL gradient
 all-reduce.  Prints ONE JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 5
+
+--workload selects the other measurement cases of SURVEY.md section 8d (same JSON contract, their own metric
+string; the headline metric is the default `wgan`): `reconstruct` (train_reconstruct phase), `cycle` (the
+README schedule 25 reconstruct : 5 discriminator : 1 generator as one step), `teacher` (configs[0]: 3-forward
+teacher step, bs16), `greedy` (configs[3]: greedy decode bs512, capped at --max-length steps because
+random-init weights never emit </s>), `long` (configs[4]: WGAN step at 128 words, bs256).
 """
 import argparse
 import json
@@ -28,11 +34,13 @@ MFMA_PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="wgan", choices=["wgan", "reconstruct", "cycle", "teacher", "greedy", "long"])
+    ap.add_argument("--max-length", type=int, default=20, help="greedy workload: decode steps per sentence")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
-    ap.add_argument("--batch", type=int, default=80)
-    ap.add_argument("--max-words", type=int, default=16)
+    ap.add_argument("--batch", type=int, default=None)
+    ap.add_argument("--max-words", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     return ap.parse_args()
@@ -106,14 +114,77 @@ def main():
 
     cfg = MSSRConfig()
     nets = build_all(cfg, device=dev, seed=123)               # same weights on every rank
-    batch = make_batch(args.batch, args.max_words, cfg.vocab_size, seed=123 + rank, device=dev)
+    wl = args.workload
+    dflt_batch = {"teacher": 16, "greedy": 512, "long": 256}.get(wl, 80)
+    dflt_words = 128 if wl == "long" else 16
+    args.batch = args.batch or dflt_batch
+    args.max_words = args.max_words or dflt_words
+    batch = make_batch(args.batch, args.max_words, cfg.vocab_size, seed=123 + rank, device=dev,
+                       min_words=64 if wl == "long" else 3)
     torch.manual_seed(1000 + rank)
     trainer = Trainer(nets, cfg, grad_sync=GradSync(world) if world > 1 else None)
+    tokens_per_step = batch.n_tokens
+    base = "12L d512 ff1024 main model, 3L style generator/teacher, text+style critics with GP, " \
+           "bs%d sentences/GPU, <=%d words, V=%d, dropout 0.1, Adam" % (args.batch, args.max_words, cfg.vocab_size)
 
-    def step():
-        d = trainer.train_discriminator(batch)
-        g = trainer.train_generator(batch)
-        return d, g
+    if wl in ("wgan", "long"):
+        metric = "train tokens/sec, MSSRNet WGAN step (12L d512, bs%d)" % args.batch
+        what = ("configs[1]" if wl == "wgan" else "configs[4] (long-sequence stress)") + \
+            ": full WGAN step = train_discriminator + train_generator, " + base
+
+        def step():
+            d = trainer.train_discriminator(batch)
+            g = trainer.train_generator(batch)
+            return d, g
+    elif wl == "reconstruct":
+        metric = "train tokens/sec, MSSRNet train_reconstruct phase (12L d512, bs%d)" % args.batch
+        what = "train_reconstruct phase alone (SURVEY 8d), " + base
+
+        def step():
+            return (trainer.train_reconstruct(batch), {})
+    elif wl == "cycle":
+        metric = "train tokens/sec, MSSRNet schedule cycle 25 reconstruct : 5 discriminator : 1 generator (bs%d)" % args.batch
+        what = "one step = the README schedule cycle (31 phase calls on the same batch), " + base
+        tokens_per_step = batch.n_tokens * 31
+
+        def step():
+            for _ in range(25):
+                r = trainer.train_reconstruct(batch)
+            for _ in range(5):
+                d = trainer.train_discriminator(batch)
+            g = trainer.train_generator(batch)
+            return ({**r, **d}, g)
+    elif wl == "teacher":
+        from mssrnet_style_transfer_amd.trainer_wgan_wh import teacher_step_loss
+        from mssrnet_style_transfer_amd.style_generator_builder import build_classifier
+        torch.manual_seed(123)
+        clf = build_classifier(cfg).to(dev)
+        clf.train()
+        t_opt = torch.optim.Adam(clf.parameters(), fused=True)
+        metric = "train tokens/sec, teacher classifier step (3L 8x32, bs%d)" % args.batch
+        what = "configs[0]: teacher step = 3 forwards (ids / ids+</s> / padded length) + backward + Adam, " \
+               "bs%d, <=%d words" % (args.batch, args.max_words)
+
+        def step():
+            t_opt.zero_grad()
+            loss, _ = teacher_step_loss(clf, batch, cfg)
+            loss.backward()
+            t_opt.step()
+            ops.params_changed(clf)
+            return ({"teacher_nll": float(loss.detach())}, {})
+    else:
+        from mssrnet_style_transfer_amd.translate import greedy_translate
+        desired = 1 - batch.labels
+        tokens_per_step = args.batch * args.max_length
+        metric = "decode tokens/sec, greedy style transfer (beam 1, bs%d)" % args.batch
+        what = "configs[3]: StyleGenerator2 + encoder + bond + greedy decode on the decode engine, bs%d, <=%d words, " \
+               "%d steps per sentence (random-init weights never emit </s>: fixed cap), ids copied to the host" % (
+                   args.batch, args.max_words, args.max_length)
+
+        def step():
+            out = greedy_translate(nets["model"], nets["style_generator"], cfg, batch.src[1:], batch.src_lengths - 1,
+                                   desired, max_length=args.max_length)
+            return ({"mean_len": sum(len(o) for o in out) / len(out)}, {})
 
     def sync():
         torch.cuda.synchronize()
@@ -129,7 +200,7 @@ def main():
         logs = step()
     sync()
     elapsed = time.perf_counter() - t0
-    tokens = torch.tensor([float(batch.n_tokens * args.steps)], device=dev)
+    tokens = torch.tensor([float(tokens_per_step * args.steps)], device=dev)
     tmax = torch.tensor([elapsed], device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -144,20 +215,17 @@ def main():
     if world > 1:
         dist.barrier()
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and wl == "wgan" and not args.no_cpu_baseline:
         cpu = cpu_baseline(nets, cfg, batch)
 
     if rank == 0:
         out = {
-            "metric": "train tokens/sec, MSSRNet WGAN step (12L d512, bs80)",
+            "metric": metric,
             "value": round(tokens / elapsed, 2), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "configs[1]: full WGAN step = train_discriminator + train_generator, "
-                                   "12L d512 ff1024 main model, 3L style generator/teacher, text+style critics with GP, "
-                                   "bs%d sentences/GPU, <=%d words, V=%d, dropout 0.1, Adam" % (
-                                       args.batch, args.max_words, cfg.vocab_size),
-                       "tokens_per_step_per_gpu": batch.n_tokens,
+            "config": {"workload": what,
+                       "tokens_per_step_per_gpu": tokens_per_step,
                        "parallelism": "dp%d (batch-sharded, bucketed RCCL grad all-reduce)" % world,
                        "losses": {k: round(v, 4) for k, v in {**logs[0], **logs[1]}.items()}},
             "roofline": roof, "cpu_baseline": cpu}

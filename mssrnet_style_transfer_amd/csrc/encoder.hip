@@ -35,8 +35,9 @@ static int enc_check(const mssr_encoder_plan* p, bool backward, const char* who)
     MSSR_REQUIRE(mssr_attention_fits(p->L, p->L, dh, p->dtype, backward ? 1 : 0),
                  "%s: L=%d, dh=%d is beyond the fused attention kernel", who, p->L, dh);
     if (p->fuse_ln) {
-        MSSR_REQUIRE(!p->save && p->dtype == MSSR_BF16 && p->d % 32 == 0 && p->d <= 2048,
-                     "%s: fuse_ln needs a forward-only bf16 plan and a model dim that is a multiple of 32, <= 2048", who);
+        MSSR_REQUIRE(!p->save && p->dtype == MSSR_BF16 && p->d % 32 == 0 && p->d <= 2048 && (int64_t)p->B * p->L <= 8192,
+                     "%s: fuse_ln needs a forward-only bf16 plan, a model dim that is a multiple of 32, <= 2048, and B*L <= 8192",
+                     who);
         for (int l = 0; l < p->n_layers; ++l) {
             const mssr_enc_layer& L = p->layers[l];
             MSSR_REQUIRE(L.wg_qkv && L.wg_1 && L.cs_qkv && L.cs_1 && L.bf_qkv && L.bf_1,

@@ -126,7 +126,7 @@ class _EncoderStack(Function):
         plan.dtype = L.F32 if cd == torch.float32 else L.BF16
         plan.B, plan.L, plan.d, plan.heads, plan.ff, plan.n_layers = B, Ln, d, spec.heads, ff, NL
         plan.save, plan.training = int(spec.save), int(spec.training)
-        plan.fuse_ln = int(pk.fuse_ln and not spec.save)
+        plan.fuse_ln = int(pk.fuse_ln and not spec.save and R <= 8192)      # the K-split GEMM (LN prologue) takes <= 8192 rows
         plan.p_drop, plan.p_attn, plan.seed = spec.p_drop, spec.p_attn, spec.seed
         plan.layers = pk.layers
         plan.lnF_g, plan.lnF_b = pk.lnF_g.data_ptr(), pk.lnF_b.data_ptr()
