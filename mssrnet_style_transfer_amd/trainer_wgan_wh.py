@@ -292,12 +292,69 @@ class Trainer:
             log.update(T_selfstyle_vloss=v[3])
         return log
 
+    def _train_reconstruct_batched(self, batch):
+        """train_reconstruct with its independent pieces batched (cfg.batch_generator_phase), as in
+        _train_generator_batched: the reference (onmt/trainer_wgan_wh.py:729-863) runs the style generator
+        twice, the main encoder three times and the soft decode twice on the same weights and source; here
+        they are one style-generator call on 2B rows, one encoder call on 3B rows (teacher-forced third
+        first) and one soft decode on 2B rows (the reconstruction half only needs the first tgt_len steps).
+        This phase is 25 of the 31 calls of the README schedule."""
+        cfg = self.cfg
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        tgt_len, B = vocab_target.size(0), vocab_target.size(1)
+        flat_target = vocab_target.contiguous().view(-1)
+        desired = 1 - labels
+        max_dec_steps = tgt_len + cfg.max_extra_dec_steps
+        real_rep = self._gen_real_style_represents(real_src, real_len)
+        rep_both = self._gen_style_represents(torch.cat([labels, desired]), real_src.repeat(1, 2, 1), real_len.repeat(2))
+        rep_src, rep_tgt = rep_both[:, :B], rep_both[:, B:]
+        src3, len3 = real_src.repeat(1, 3, 1), real_len.repeat(3)
+        enc_state, mem, lengths = self._encode(src3, len3, torch.cat([real_rep.to(rep_both.dtype), rep_both], 1))
+        # teacher-forced self reconstruction on the first third
+        self.model.decoder.init_state(real_src, mem[:, :B], enc_state[:, :B])
+        dec_out, _ = self.model.decoder(batch.tgt, mem[:, :B], memory_lengths=lengths[:B])
+        lp = generator_probs(self.model, dec_out, cfg.dec_temperature, log=True)
+        l_noised = self.vocab_loss(lp.view(-1, lp.size(-1)), flat_target, B)
+        # both soft decodes at once
+        src2, len2 = src3[:, B:], len3[B:]
+        self.model.decoder.init_state(src2, mem[:, B:], enc_state[:, B:])
+        probs_all = soft_decode(self.model, cfg, mem[:, B:], len2, max_dec_steps)
+        probs, cprobs = probs_all[:tgt_len, :B], probs_all[:, B:]
+        l_rec = self.vocab_loss_from_probs(probs, flat_target, B)
+        total = cfg.sr_loss_ratio * l_noised + cfg.sr_loss_ratio * l_rec
+        s_src = self.classifier.do_cls(rep_src.transpose(0, 1), real_len)
+        l_s_src = F.nll_loss(F.log_softmax(s_src, -1), labels)
+        s_tgt = self.classifier.do_cls(rep_tgt.transpose(0, 1), real_len)
+        l_s_tgt = F.nll_loss(F.log_softmax(s_tgt, -1), desired)
+        total = total + cfg.cls_loss_ratio * l_s_src + cfg.cls_loss_ratio * l_s_tgt
+        names, vals = ["T_CONSTRUCT_R_VL", "T_CONSTRUCT_F_VL"], [l_noised, l_rec]
+        if not cfg.without_stl_penalty:
+            l_gap = self.cal_style_gap(real_rep, rep_src, real_len)
+            total = total + cfg.alpha_style_gap * l_gap
+        clens_list, _ = fetch_dec_output_length(cprobs, cfg)
+        clens = torch.tensor(clens_list, dtype=torch.long, device=real_len.device)
+        t_logits = self.classifier(cprobs, clens)
+        l_t = F.nll_loss(F.log_softmax(t_logits, -1), desired)
+        total = total + cfg.cls_loss_ratio * l_t
+        names += ["T_CLS_loss", "T_CLS_acc", "S_CLS_loss", "S_CLS_acc", "SCur_CLS_loss", "SCur_CLS_acc"]
+        vals += [l_t, t_logits.argmax(-1).eq(desired).float().mean(), l_s_tgt,
+                 s_tgt.argmax(-1).eq(desired).float().mean(), l_s_src, s_src.argmax(-1).eq(labels).float().mean()]
+        if not cfg.without_stl_penalty:
+            names.append("S_GAP_loss")
+            vals.append(l_gap)
+        self._arm(self.style_generator, self.model)
+        total.backward()
+        self._finish((self.style_generator, self.model), [self.style_generator_optim, self.model_optim], clip=False)
+        return dict(zip(names, torch.stack([t.detach().float() for t in vals]).tolist()))
+
     def train_reconstruct(self, batch):
         cfg = self.cfg
         self.style_generator.train()
         self.model.train()
         self.style_generator_optim.zero_grad()
         self.model_optim.zero_grad()
+        if cfg.batch_generator_phase and cfg.use_cls_feedback and cfg.sr_noise_prob == 0:
+            return self._train_reconstruct_batched(batch)
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
         tgt_len, B = vocab_target.size(0), vocab_target.size(1)
         flat_target = vocab_target.contiguous().view(-1)

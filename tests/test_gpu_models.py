@@ -125,6 +125,23 @@ def test_generator_phase_reference_order_fp32(ops, golden_phases):
         assert_grads(grads_of(nets[n]), c["grads"][n], 2e-4, "generator(ref order)." + n)
 
 
+def test_reconstruct_phase_reference_order_fp32(ops, golden_phases):
+    """train_reconstruct in the reference's own call order (two style-generator calls, three encoder calls,
+    two decodes: batch_generator_phase = False) against the same golden vectors."""
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    cfg = MSSRConfig.small(batch_generator_phase=False)
+    nets = make_nets(golden_phases, cfg)
+    tr = Trainer(nets, cfg)
+    c = golden_phases["reconstruct"]
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    log = tr.train_reconstruct(gpu_batch(golden_phases))
+    for k, v in c["scalars"].items():
+        assert abs(log[k] - v) <= TOL * max(abs(v), 1e-3), (k, log[k], v)
+    for n in ("model", "style_generator"):
+        assert_grads(grads_of(nets[n]), c["grads"][n], 2e-4, "reconstruct(ref order)." + n)
+
+
 @pytest.mark.parametrize("name,fn,trained", PHASES)
 def test_phase_fp32(ops, golden_phases, name, fn, trained):
     from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
