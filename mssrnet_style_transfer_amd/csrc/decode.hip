@@ -14,6 +14,7 @@
 #include "engine_common.hpp"
 #include <stdlib.h>
 #include <thread>
+#include <initializer_list>
 
 namespace mssr {
 
@@ -235,6 +236,368 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     }
 }
 
+// ------------------------------------------------------------------ tiled single-query attention
+// Same math as the two kernels above with a different lane mapping: every lane moves 16 bytes per load, LPR =
+// dh / E lanes cover one key / value row (E = elements per 16 bytes) and a wave covers 64 / LPR rows per load
+// instruction; AT_NL instructions (a "chunk" of rows) are in flight together.  Every address of the first chunk
+// of K, of V (and, in the backward, of the later steps' q / dctx rows and slab coefficients) is known at kernel
+// start, so for up to 64 bf16 rows the whole kernel exposes ONE memory round trip; the one-row-per-lane kernels
+// above issue Lk dependent 2-byte loads in their lane <-> feature phases (measured at 140 keys: 55 / 140 us).
+constexpr int AT_NL = 8;
+
+template <typename T> struct Row16;
+template <> struct Row16<bf16> {
+    static constexpr int E = 8;
+    typedef bf16x8 V;
+    static __device__ __forceinline__ V load(const bf16* p) { return *reinterpret_cast<const V*>(p); }
+    static __device__ __forceinline__ void store(bf16* p, const float (&o)[8]) {
+        V v;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (bf16)o[i];
+        *reinterpret_cast<V*>(p) = v;
+    }
+};
+template <> struct Row16<float> {
+    static constexpr int E = 4;
+    typedef f32x4 V;
+    static __device__ __forceinline__ V load(const float* p) { return *reinterpret_cast<const V*>(p); }
+    static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+        V v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = o[i];
+        *reinterpret_cast<V*>(p) = v;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ float dot16(const typename Row16<T>::V& a, const typename Row16<T>::V& b) {
+    float r = 0.f;
+#pragma unroll
+    for (int e = 0; e < Row16<T>::E; ++e) r += (float)a[e] * (float)b[e];
+    return r;
+}
+
+// sum over the 2^LS adjacent lanes that hold one row (every lane of the group gets the total): DPP moves, no LDS
+// crossbar trip (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
+template <int LS>
+__device__ __forceinline__ float group_sum(float v) {
+    if (LS >= 1) v += dpp_mov<0xB1>(v);
+    if (LS >= 2) v += dpp_mov<0x4E>(v);
+    if (LS >= 3) v += dpp_mov<0x141>(v);
+    if (LS >= 4) v += dpp_mov<0x140>(v);
+    return v;
+}
+// the value of lane ^ O: data-parallel moves where one exists for the pattern, the LDS crossbar otherwise
+template <int O>
+__device__ __forceinline__ float xor_get(float v) {
+    if constexpr (O == 1) return dpp_mov<0xB1>(v);
+    else if constexpr (O == 2) return dpp_mov<0x4E>(v);
+    else if constexpr (O == 8) return dpp_mov<0x128>(v);      // row_ror:8 == xor 8 inside a 16-lane row
+    else return __shfl_xor(v, O, 64);
+}
+// sum over the 64 >> LS row groups of a wave (lanes that differ in bits LS..5), N independent values
+template <int LS, int N>
+__device__ __forceinline__ void cross_group_sum(float (&a)[N]) {
+#define MSSR_XSTEP(O)                                       \
+    if constexpr ((1 << LS) <= O) {                         \
+        _Pragma("unroll") for (int n = 0; n < N; ++n) a[n] += xor_get<O>(a[n]); \
+    }
+    MSSR_XSTEP(1)
+    MSSR_XSTEP(2)
+    MSSR_XSTEP(4)
+    MSSR_XSTEP(8)
+    MSSR_XSTEP(16)
+    MSSR_XSTEP(32)
+#undef MSSR_XSTEP
+}
+
+// rows t0 + i*RPL + r (clamped to n_rows - 1) of a [n_rows, dh] operand with row stride `rs`; `base` already
+// points at this lane's 16-byte column group
+template <typename T>
+__device__ __forceinline__ void load_chunk(typename Row16<T>::V (&dst)[AT_NL], const T* base, int64_t rs, int t0, int r,
+                                           int RPL, int n_rows) {
+#pragma unroll
+    for (int i = 0; i < AT_NL; ++i) {
+        int t = t0 + i * RPL + r;
+        t = t < n_rows ? t : n_rows - 1;
+        dst[i] = Row16<T>::load(base + (int64_t)t * rs);
+    }
+}
+
+template <typename T, int LS>
+__global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
+    const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
+    int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
+    int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    typedef Row16<T> R;
+    typedef typename R::V V;
+    constexpr int E = R::E;
+    __shared__ float sc[4][AT_MAXK];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh_raw = blockIdx.x * 4 + wave;
+    const bool active = bh_raw < B * H;
+    const int bh = active ? bh_raw : B * H - 1;
+    const int b = bh / H, h = bh % H;
+    constexpr int LPR = 1 << LS, RPL = 64 >> LS, RC = AT_NL * RPL;
+    const int c = lane & (LPR - 1), r = lane >> LS;
+    const T* qp = q + (int64_t)b * q_bs + h * dh + c * E;
+    const T* kp = k + (int64_t)b * kv_bs + h * dh + c * E;
+    const T* vp = v + (int64_t)b * kv_bs + h * dh + c * E;
+    float* s = sc[wave];
+    V k0[AT_NL], v0[AT_NL];
+    load_chunk<T>(k0, kp, kv_ts, 0, r, RPL, Lk);
+    load_chunk<T>(v0, vp, kv_ts, 0, r, RPL, Lk);
+    const V qf = R::load(qp);
+    const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
+
+    auto scores = [&](const V (&kt)[AT_NL], int t0) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= Lk) break;                  // uniform: the rest of the chunk is past the last key
+            const float a = group_sum<LS>(dot16<T>(kt[i], qf));
+            const int t = t0 + i * RPL + r;
+            if (c == 0 && t < Lk) s[t] = a * scale;
+        }
+    };
+    scores(k0, 0);
+    for (int t0 = RC; t0 < Lk; t0 += RC) {
+        V kt[AT_NL];
+        load_chunk<T>(kt, kp, kv_ts, t0, r, RPL, Lk);
+        scores(kt, t0);
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = lane; t < Lk; t += 64) {
+        float a = s[t];
+        const bool masked = mask && (t < 64 ? mk0 : mask[(int64_t)b * mask_bs + t]);
+        if (masked) a = -1e18f;
+        s[t] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Lk; t += 64) {
+        const float e = expf(s[t] - mx);
+        s[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    for (int t = lane; t < Lk; t += 64) {
+        float p = s[t] * inv;
+        if (p_drop > 0.f) p = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? p * keep_scale : 0.f;
+        s[t] = p;
+    }
+    __syncthreads();
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    auto ctxacc = [&](const V (&vt)[AT_NL], int t0) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= Lk) break;
+            const int t = t0 + i * RPL + r;
+            const float pt = t < Lk ? s[t] : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += pt * (float)vt[i][e];
+        }
+    };
+    ctxacc(v0, 0);
+    for (int t0 = RC; t0 < Lk; t0 += RC) {
+        V vt[AT_NL];
+        load_chunk<T>(vt, vp, kv_ts, t0, r, RPL, Lk);
+        ctxacc(vt, t0);
+    }
+    cross_group_sum<LS, E>(acc);
+    if (active && r == 0) R::store(ctx + (int64_t)b * ctx_bs + h * dh + c * E, acc);
+}
+
+// Backward (see attn_step_bwd_kernel for the math and the gather form): chunk 0 of K, V, of the later steps'
+// q / dctx rows and the slab coefficients are all requested before the first use.
+template <typename T, int LS>
+__global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
+    const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
+    int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
+    T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
+    int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
+    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    typedef Row16<T> R;
+    typedef typename R::V V;
+    constexpr int E = R::E;
+    __shared__ float s_p[4][AT_MAXK];      // scores, p, then ds
+    __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p); then the ds coefficients of steps step .. T-1
+    __shared__ float s_pd[4][AT_MAXK];     // dropped p; then the pd coefficients of steps step .. T-1
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int bh_raw = blockIdx.x * 4 + wave;
+    const bool active = bh_raw < B * H;
+    const int bh = active ? bh_raw : B * H - 1;
+    const int b = bh / H, h = bh % H;
+    constexpr int LPR = 1 << LS, RPL = 64 >> LS, RC = AT_NL * RPL;
+    const int c = lane & (LPR - 1), r = lane >> LS;
+    const T* qp = q + (int64_t)b * q_bs + h * dh + c * E;
+    const T* kp = k + (int64_t)b * kv_bs + h * dh + c * E;
+    const T* vp = v + (int64_t)b * kv_bs + h * dh + c * E;
+    const T* dcp = dctx + (int64_t)b * dctx_bs + h * dh + c * E;
+    float* dso = ds_out + (int64_t)bh * slab_bhs;
+    float* pdo = pd_out + (int64_t)bh * slab_bhs;
+    float* s = s_p[wave];
+    float* dpv = s_dp[wave];
+    float* pdv = s_pd[wave];
+    const int n_rows = gather ? n_steps - step : 0;      // this step and the later ones
+
+    V k0[AT_NL], v0[AT_NL], q0[AT_NL], d0[AT_NL];
+    load_chunk<T>(k0, kp, kv_ts, 0, r, RPL, Lk);
+    load_chunk<T>(v0, vp, kv_ts, 0, r, RPL, Lk);
+    const V qf = R::load(qp);
+    const V df = R::load(dcp);
+    const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
+    float ck0 = 0.f, cv0 = 0.f;
+    if (gather) {
+        load_chunk<T>(q0, qp, q_ss, 0, r, RPL, n_rows);
+        load_chunk<T>(d0, dcp, dctx_ss, 0, r, RPL, n_rows);
+        const int i = lane >= 1 && lane < n_rows ? lane : (n_rows > 1 ? 1 : 0);
+        if (n_rows > 1) {                       // slabs of the later steps exist (written by earlier launches)
+            ck0 = dso[(int64_t)i * slab_ss + step];
+            cv0 = pdo[(int64_t)i * slab_ss + step];
+        }
+    }
+
+    auto phase_a = [&](const V (&kt)[AT_NL], const V (&vt)[AT_NL], int t0) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= Lk) break;
+            const float a = group_sum<LS>(dot16<T>(kt[i], qf));
+            const float g = group_sum<LS>(dot16<T>(vt[i], df));
+            const int t = t0 + i * RPL + r;
+            if (c == 0 && t < Lk) {
+                s[t] = a * scale;
+                dpv[t] = g;
+            }
+        }
+    };
+    phase_a(k0, v0, 0);
+    for (int t0 = RC; t0 < Lk; t0 += RC) {
+        V kt[AT_NL], vt[AT_NL];
+        load_chunk<T>(kt, kp, kv_ts, t0, r, RPL, Lk);
+        load_chunk<T>(vt, vp, kv_ts, t0, r, RPL, Lk);
+        phase_a(kt, vt, t0);
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int t = lane; t < Lk; t += 64) {
+        float a = s[t];
+        const bool masked = mask && (t < 64 ? mk0 : mask[(int64_t)b * mask_bs + t]);
+        if (masked) a = -1e18f;
+        s[t] = a;
+        mx = fmaxf(mx, a);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int t = lane; t < Lk; t += 64) {
+        const float e = expf(s[t] - mx);
+        s[t] = e;
+        sum += e;
+    }
+    sum = wave_sum(sum);
+    const float inv = 1.0f / sum;
+    const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    float rr = 0.f;
+    for (int t = lane; t < Lk; t += 64) {
+        const float p = s[t] * inv;
+        float m = 1.0f;
+        if (p_drop > 0.f) m = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? keep_scale : 0.f;
+        const float dp = dpv[t] * m;
+        s[t] = p;
+        dpv[t] = dp;
+        pdv[t] = p * m;
+        if (active) pdo[t] = p * m;
+        rr += p * dp;
+    }
+    rr = wave_sum(rr);
+    for (int t = lane; t < Lk; t += 64) {
+        float ds = s[t] * (dpv[t] - rr) * scale;
+        const bool masked = mask && (t < 64 ? mk0 : mask[(int64_t)b * mask_bs + t]);
+        if (masked) ds = 0.f;                    // masked_fill: no gradient to the score
+        s[t] = ds;
+        if (active) dso[t] = ds;
+    }
+    __syncthreads();
+    const float ds_own = gather ? s[step] : 0.f;
+    const float pd_own = gather ? pdv[step] : 0.f;
+    __syncthreads();
+    if (gather) {                                // coefficient of row `step` in the slab of step step + i
+        if (lane == 0) {
+            dpv[0] = ds_own;
+            pdv[0] = pd_own;
+        } else if (lane < n_rows) {
+            dpv[lane] = ck0;
+            pdv[lane] = cv0;
+        }
+        for (int i = lane + 64; i < n_rows; i += 64) {
+            dpv[i] = dso[(int64_t)i * slab_ss + step];
+            pdv[i] = pdo[(int64_t)i * slab_ss + step];
+        }
+    }
+    __syncthreads();
+    // dq = sum_t ds_t K[t]
+    float acc[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) acc[e] = 0.f;
+    auto dqacc = [&](const V (&kt)[AT_NL], int t0) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= Lk) break;
+            const int t = t0 + i * RPL + r;
+            const float w = t < Lk ? s[t] : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) acc[e] += w * (float)kt[i][e];
+        }
+    };
+    dqacc(k0, 0);
+    for (int t0 = RC; t0 < Lk; t0 += RC) {
+        V kt[AT_NL];
+        load_chunk<T>(kt, kp, kv_ts, t0, r, RPL, Lk);
+        dqacc(kt, t0);
+    }
+    cross_group_sum<LS, E>(acc);
+    if (active && r == 0) R::store(dq + (int64_t)b * dq_bs + h * dh + c * E, acc);
+    if (!gather) return;
+    // dK[step] = sum_i ds_{step+i}[step] q_{step+i} ; dV[step] = sum_i pd_{step+i}[step] dctx_{step+i}
+    float gk[E], gv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) gk[e] = gv[e] = 0.f;
+    auto gacc = [&](const V (&qt)[AT_NL], const V (&dt)[AT_NL], int t0) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= n_rows) break;
+            const int t = t0 + i * RPL + r;
+            const float wk = t < n_rows ? dpv[t] : 0.f;
+            const float wv = t < n_rows ? pdv[t] : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                gk[e] += wk * (float)qt[i][e];
+                gv[e] += wv * (float)dt[i][e];
+            }
+        }
+    };
+    gacc(q0, d0, 0);
+    for (int t0 = RC; t0 < n_rows; t0 += RC) {
+        V qt[AT_NL], dt[AT_NL];
+        load_chunk<T>(qt, qp, q_ss, t0, r, RPL, n_rows);
+        load_chunk<T>(dt, dcp, dctx_ss, t0, r, RPL, n_rows);
+        gacc(qt, dt, t0);
+    }
+    cross_group_sum<LS, E>(gk);
+    cross_group_sum<LS, E>(gv);
+    if (active && r == 0) {
+        R::store(dk_out + (int64_t)b * out_bs + h * dh + c * E, gk);
+        R::store(dv_out + (int64_t)b * out_bs + h * dh + c * E, gv);
+    }
+}
+
 // x0 = dropout(e * s + pe[step])   (Embeddings soft path epilogue, onmt/modules/embeddings.py:48-53)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict__ e, const float* __restrict__ pe,
@@ -328,6 +691,28 @@ static inline uint64_t site_seed(const Ctx& c, int step, int layer, int site) {
            (uint64_t)site * 7919ull + (uint64_t)c.chunk * 0xC2B2AE3D27D4EB4Full;
 }
 
+// log2(lanes per row) when the tiled kernels apply: dh = E * 2^k with k = 1..4, every pointer 16-byte aligned and every
+// stride a multiple of E elements (E = elements per 16 bytes); -1 otherwise (one-row-per-lane kernels)
+template <typename T>
+static int tiled_shift(int dh, std::initializer_list<const void*> ptrs, std::initializer_list<int64_t> strides) {
+    static const bool enabled = [] {
+        const char* e = getenv("MSSR_ATTN_STEP_TILED");
+        return !(e && e[0] == '0');
+    }();
+    if (!enabled) return -1;
+    constexpr int E = 16 / (int)sizeof(T);
+    if (dh % E != 0) return -1;
+    const int lpr = dh / E;
+    if (lpr < 1 || lpr > 64 || (lpr & (lpr - 1)) != 0) return -1;
+    for (const void* q : ptrs)
+        if (q && !aligned(q, 16)) return -1;
+    for (int64_t st : strides)
+        if (st % E != 0) return -1;
+    int sh = 0;
+    while ((1 << sh) < lpr) ++sh;
+    return sh;
+}
+
 template <typename T>
 static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const void* k, const void* v, int64_t kv_bs,
                             int64_t kv_ts, const uint8_t* mask, int64_t mask_bs, void* ctx, int64_t ctx_bs, int Lk,
@@ -335,6 +720,19 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     const mssr_decode_plan* p = c.p;
     const int dh = p->d / p->heads;
     const int bh = c.Bc * p->heads;
+    const int sh = tiled_shift<T>(dh, {q, k, v, ctx}, {q_bs, kv_bs, kv_ts, ctx_bs});
+#define MSSR_FWD_TILED(LS)                                                                                          \
+    attn_step_fwd_tiled_kernel<T, LS><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                        \
+        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh, \
+        Lk, 1.0f / sqrtf((float)dh), p_drop, seed)
+    switch (sh) {
+        case 1: MSSR_FWD_TILED(1); return;
+        case 2: MSSR_FWD_TILED(2); return;
+        case 3: MSSR_FWD_TILED(3); return;
+        case 4: MSSR_FWD_TILED(4); return;
+        default: break;
+    }
+#undef MSSR_FWD_TILED
     attn_step_fwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh,
         Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
@@ -349,6 +747,21 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     const mssr_decode_plan* p = c.p;
     const int dh = p->d / p->heads;
     const int bh = c.Bc * p->heads;
+    const int sh = tiled_shift<T>(dh, {q, k, v, dctx, dq, dk_out, dv_out},
+                                  {q_bs, kv_bs, kv_ts, dctx_bs, dq_bs, q_ss, dctx_ss, out_bs});
+#define MSSR_BWD_TILED(LS)                                                                                          \
+    attn_step_bwd_tiled_kernel<T, LS><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                        \
+        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,    \
+        dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,  \
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed)
+    switch (sh) {
+        case 1: MSSR_BWD_TILED(1); return;
+        case 2: MSSR_BWD_TILED(2); return;
+        case 3: MSSR_BWD_TILED(3); return;
+        case 4: MSSR_BWD_TILED(4); return;
+        default: break;
+    }
+#undef MSSR_BWD_TILED
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,
