@@ -192,6 +192,39 @@ def stop_profile():
     return out
 
 
+_tpad_cache = {}
+
+
+def _cast_t_pad(p, kp):
+    """bf16 copy of the parameter p [K, N] as [N, kp] (k-contiguous, zero columns K..kp), cached like cast()."""
+    key = id(p)
+    ver = (p._version, _param_epoch.get(key, 0), kp)
+    hit = _tpad_cache.get(key)
+    if hit is not None and hit[0]() is p and hit[1] == ver and hit[2] == p.data_ptr():
+        return hit[3]
+    K, N = p.shape
+    t = torch.zeros(N, kp, dtype=torch.bfloat16, device=p.device)
+    t[:, :K].copy_(p.detach().t())
+    _tpad_cache[key] = (weakref.ref(p), ver, p.data_ptr(), t)
+    return t
+
+
+def _long_k_nn(a, w, out_dtype):
+    """a [M, K] @ w [K, N] with a vocabulary-sized K (soft embedding of the critics, onmt/modules/embeddings.py:
+    278-280: probabilities times the table).  The table is n-contiguous and K = 9606 rows are not 16-byte
+    aligned in bf16, which leaves only the general kernel's serial K loop (440 us at 1440 x 256 x 9606); with the
+    operand cast into a K-padded buffer (the cast is needed anyway) and a cached transposed table the split-K
+    MFMA kernel applies (both operands k-contiguous)."""
+    M, K = a.shape
+    kp = (K + 31) // 32 * 32
+    wt = _cast_t_pad(w, kp)
+    ap = torch.empty(M, kp, dtype=torch.bfloat16, device=a.device)
+    ap[:, :K].copy_(a.detach())
+    if kp > K:
+        ap[:, K:].zero_()
+    return gemm(ap, wt, True, out_dtype)
+
+
 class _Matmul(Function):
     """C = A @ B (tb=False, B [.., K, N]) or A @ B^T (tb=True, B [.., N, K]); closed under autograd."""
 
@@ -199,6 +232,9 @@ class _Matmul(Function):
     def forward(ctx, a, b, tb, out_dtype, heads_last=False):
         ctx.save_for_backward(a, b)
         ctx.tb = tb
+        if (not tb and not heads_last and a.dim() == 2 and b.dim() == 2 and isinstance(b, torch.nn.Parameter)
+                and b.shape[0] > 2048 and _state["dtype"] == torch.bfloat16 and a.is_cuda):
+            return _long_k_nn(a, b, out_dtype or _state["dtype"])
         ac, bc = cast(a), cast(b)
         out = None
         if heads_last:          # [B,H,M,N] result stored as [B,M,H,N] (the "unshape" layout, mha.py:126-129)
