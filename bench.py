@@ -47,8 +47,10 @@ def parse():
 
 
 def roofline(records, dtype):
-    """Dominant GEMM kernel instance of one instrumented step: algorithmic bytes (or flops) of all
-    its launches / the sum of their HIP-event durations."""
+    """Dominant GEMM kernel instance of one instrumented step: algorithmic bytes (or flops) of all its
+    launches / the sum of their durations.  Durations are HIP events handed to hipExtLaunchKernelGGL
+    (mssr_prof_*, csrc/core.hip): begin / end of the dispatch itself on the launch stream, the interval
+    rocprofv3's kernel trace reports."""
     agg = {}
     for r in records:
         a = agg.setdefault(r["kernel"], dict(ms=0.0, bytes=0, flops=0, launches=0, key=r["in_dtype"]))
@@ -69,6 +71,7 @@ def roofline(records, dtype):
     # traffic: HBM bytes from rocprofv3 PMC counters need a separate profiler pass; not collected in-process
     return dict(bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 5), traffic=None,
                 kernel=name, launches_per_step=a["launches"], avg_launch_us=round(a["ms"] * 1e3 / a["launches"], 2),
+
                 algorithmic_bytes_per_launch=int(a["bytes"] / a["launches"]),
                 gemm_time_share={k: round(v["ms"], 3) for k, v in sorted(agg.items())})
 

@@ -113,8 +113,9 @@ int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);
 int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
 
 /* Launch timing for the benchmark's roofline (no reference counterpart): between mssr_prof_start
- * and mssr_prof_stop every mssr_gemm launch -- direct or from inside the decode engine -- is
- * bracketed by HIP events on the stream it is enqueued on.  kernel: 0 = gemm_kernel (tile = 32/64),
+ * and mssr_prof_stop every mssr_gemm launch -- direct or from inside the decode engine -- is timed with a HIP
+ * event pair handed to hipExtLaunchKernelGGL on the stream it is enqueued on (begin / end of the dispatch
+ * itself, the interval rocprofv3's kernel trace reports; ms < 0: nothing was launched).  kernel: 0 = gemm_kernel (tile = 32/64),
  * 1 = gemm_skinny_kernel (tile = 16/32 output tile edge, ksplit = split-K slabs, ln = LayerNorm prologue),
  * 2 = gemm_tn_kernel (both operands k-major: weight gradients).
  * Host-side only. */

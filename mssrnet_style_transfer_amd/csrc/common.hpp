@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels of libmssr_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -14,6 +15,16 @@ void set_error(const char* fmt, ...);
 int prof_begin(hipStream_t s);
 void prof_end(int i, hipStream_t s, int kernel, int in_dt, int out_dt, int tile, int64_t batch, int64_t m, int64_t n,
               int64_t k, int ksplit = 1, int ln = 0);
+// Profiling launches: prof_begin arms the calling thread with the record's event pair and the NEXT klaunch hands
+// it to hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end times (the same
+// clock rocprofv3's kernel trace reads), so a record holds the kernel alone and not the markers around it.
+bool prof_take(hipEvent_t* start, hipEvent_t* stop);
+template <typename... KArgs, typename... Args>
+inline void klaunch(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, Args... args) {
+    hipEvent_t e0, e1;
+    if (prof_take(&e0, &e1)) hipExtLaunchKernelGGL(kern, grid, block, shmem, s, e0, e1, 0, args...);
+    else kern<<<grid, block, shmem, s>>>(args...);
+}
 
 #define MSSR_REQUIRE(cond, ...)                 \
     do {                                        \

@@ -24,19 +24,31 @@ struct ProfState {
 };
 static ProfState g_prof;
 
+static thread_local int tl_armed = -1;
+
 int prof_begin(hipStream_t s) {
     ProfState& P = g_prof;
     if (!P.on) return -1;
     const int i = P.n.fetch_add(1);
     if (i >= P.cap) return -1;
-    (void)hipEventRecord(P.ev[2 * i], s);
+    tl_armed = i;
     return i;
+}
+bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
+    if (tl_armed < 0) return false;
+    ProfState& P = g_prof;
+    const int i = tl_armed;
+    tl_armed = -1;
+    if (!P.on || i >= P.cap) return false;
+    *start = P.ev[2 * i];
+    *stop = P.ev[2 * i + 1];
+    return true;
 }
 void prof_end(int i, hipStream_t s, int kernel, int in_dt, int out_dt, int tile, int64_t batch, int64_t m, int64_t n,
               int64_t k, int ksplit, int ln) {
     if (i < 0) return;
     ProfState& P = g_prof;
-    (void)hipEventRecord(P.ev[2 * i + 1], s);
+    tl_armed = -1;                  // a path that launched nothing profiled leaves ms = -1
     mssr_prof_record& r = P.rec[i];
     r.kernel = kernel; r.in_dtype = in_dt; r.out_dtype = out_dt; r.tile = tile;
     r.batch = batch; r.m = m; r.n = n; r.k = k; r.ms = -1.f; r.ksplit = ksplit; r.ln = ln;

@@ -174,10 +174,10 @@ template <typename TI, typename TO>
 static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
     if (use_tile64(a.m, a.n, batch)) {
         dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 63) / 64), (unsigned)batch);
-        gemm_kernel<TI, TO, 64, 64><<<grid, dim3(GEMM_THREADS), 0, s>>>(a);
+        klaunch(gemm_kernel<TI, TO, 64, 64>, grid, dim3(GEMM_THREADS), 0, s, a);
     } else {
         dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)batch);
-        gemm_kernel<TI, TO, 32, 32><<<grid, dim3(GEMM_THREADS), 0, s>>>(a);
+        klaunch(gemm_kernel<TI, TO, 32, 32>, grid, dim3(GEMM_THREADS), 0, s, a);
     }
 }
 

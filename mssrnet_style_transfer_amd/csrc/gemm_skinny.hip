@@ -220,12 +220,12 @@ template <typename TO>
 static void skinny_launch(const GemmArgs& a, hipStream_t s) {
     if (gemm_skinny_tile(a.m, a.n, a.k) == 16) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
-        if (a.ln_colsum) gemm_skinny_kernel<TO, true, 1><<<grid, SK_THREADS, 0, s>>>(a);
-        else gemm_skinny_kernel<TO, false, 1><<<grid, SK_THREADS, 0, s>>>(a);
+        if (a.ln_colsum) klaunch(gemm_skinny_kernel<TO, true, 1>, grid, dim3(SK_THREADS), 0, s, a);
+        else klaunch(gemm_skinny_kernel<TO, false, 1>, grid, dim3(SK_THREADS), 0, s, a);
     } else {
         const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
-        if (a.ln_colsum) gemm_skinny_kernel<TO, true, 2><<<grid, SK_THREADS, 0, s>>>(a);
-        else gemm_skinny_kernel<TO, false, 2><<<grid, SK_THREADS, 0, s>>>(a);
+        if (a.ln_colsum) klaunch(gemm_skinny_kernel<TO, true, 2>, grid, dim3(SK_THREADS), 0, s, a);
+        else klaunch(gemm_skinny_kernel<TO, false, 2>, grid, dim3(SK_THREADS), 0, s, a);
     }
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;

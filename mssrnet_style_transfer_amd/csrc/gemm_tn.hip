@@ -164,12 +164,12 @@ bool gemm_tn_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, 
     if ((g.m + 31) / 32 > 65535 || batch > 65535) return false;
     if (tiles64 >= 128) {
         const dim3 grid((unsigned)((g.n + 63) / 64), (unsigned)((g.m + 63) / 64), (unsigned)batch);
-        if (out_dtype == MSSR_F32) gemm_tn_kernel<float, 64><<<grid, TN_THREADS, 0, s>>>(t);
-        else gemm_tn_kernel<bf16, 64><<<grid, TN_THREADS, 0, s>>>(t);
+        if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 64>, grid, dim3(TN_THREADS), 0, s, t);
+        else klaunch(gemm_tn_kernel<bf16, 64>, grid, dim3(TN_THREADS), 0, s, t);
     } else {
         const dim3 grid((unsigned)((g.n + 31) / 32), (unsigned)((g.m + 31) / 32), (unsigned)batch);
-        if (out_dtype == MSSR_F32) gemm_tn_kernel<float, 32><<<grid, TN_THREADS, 0, s>>>(t);
-        else gemm_tn_kernel<bf16, 32><<<grid, TN_THREADS, 0, s>>>(t);
+        if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 32>, grid, dim3(TN_THREADS), 0, s, t);
+        else klaunch(gemm_tn_kernel<bf16, 32>, grid, dim3(TN_THREADS), 0, s, t);
     }
     return true;
 }

@@ -186,6 +186,8 @@ def stop_profile():
                                                       "+splitK" if r.ksplit > 1 else "")
         else:
             name = "gemm_kernel<%s,%s,%d>" % (tin, tout, r.tile)
+        if r.ms < 0:
+            continue
         out.append(dict(kernel=name, in_dtype=tin, shape=(r.batch, r.m, r.n, r.k), ms=r.ms,
                         bytes=r.batch * ((r.m * r.k + r.k * r.n) * isz + r.m * r.n * osz),
                         flops=2 * r.batch * r.m * r.n * r.k))
