@@ -8,6 +8,7 @@ softmax carry hand-written second-order kernels.  torch is used for memory, view
 autograd book-keeping only; all arithmetic on activations runs in libmssr_hip.so.
 """
 import math
+import threading
 import weakref
 
 import torch
@@ -29,6 +30,9 @@ def set_compute_dtype(dtype):
 
 def compute_dtype():
     return _state["dtype"]
+
+
+_tls = threading.local()        # per Python thread: second_order flag
 
 
 def next_seed():
@@ -103,11 +107,13 @@ def _batch(t):
 
 
 def _workspace(device):
-    """Persistent fp32 scratch for the split-K slabs of the skinny-M GEMM (one per device)."""
+    """Persistent fp32 scratch for the split-K slabs of the skinny-M GEMM: one per (device, stream), launches
+    on one stream are ordered, launches on different streams must not share it."""
     ws = _state.setdefault("ws", {})
-    t = ws.get(device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    t = ws.get(key)
     if t is None:
-        t = ws[device] = torch.empty(8 << 20, dtype=torch.float32, device=device)
+        t = ws[key] = torch.empty(8 << 20, dtype=torch.float32, device=device)
     return t
 
 
@@ -660,15 +666,15 @@ class second_order:
     matmul / softmax / dropout ops above, every one of which has a differentiable backward."""
 
     def __enter__(self):
-        self.prev = _state.get("second_order", False)
-        _state["second_order"] = True
+        self.prev = getattr(_tls, "second_order", False)
+        _tls.second_order = True          # per thread: only forward-time dispatch reads it
 
     def __exit__(self, *exc):
-        _state["second_order"] = self.prev
+        _tls.second_order = self.prev
 
 
 def second_order_active():
-    return _state.get("second_order", False)
+    return getattr(_tls, "second_order", False)
 
 
 def _head_view_ok(t):

@@ -84,6 +84,13 @@ class GradSync:
             b["launched"] = True
             return
         flat = b["flat"]
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = flat.cpu()                        # blocking copy: the bucket is final
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            flat.copy_(host)
+            b["launched"] = True
+            self._pending.append((b, None))
+            return
         side = self._side_stream(flat.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(flat.device))
@@ -95,9 +102,18 @@ class GradSync:
         self._pending.append((b, work))
 
     # ---------------------------------------------------------------- overlap path
+    def _overlap_ok(self, module):
+        """Collectives are launched from gradient hooks only where the launch is a pure enqueue (RCCL on device
+        tensors, gloo on host tensors).  gloo on DEVICE tensors -- the transport of the one-GPU tests -- runs
+        worker threads that block in stream-synchronize and stalled against a host that is thousands of
+        launches ahead of the GPU (ranks stuck in the KFD event wait); that combination is reduced at the
+        phase's final sync, staged through host memory (_launch)."""
+        p = next(module.parameters(), None)
+        return not (p is not None and p.is_cuda and dist.get_backend(self.group) == "gloo")
+
     def arm(self, module):
         """Hook the next backward through ``module``: buckets are reduced as they fill."""
-        if self.world <= 1:
+        if self.world <= 1 or not self._overlap_ok(module):
             return
         plan = self._plan(module)
         for b in plan:
@@ -123,7 +139,8 @@ class GradSync:
                     self._fill(b)            # parameters whose hook never fired keep / get zeros
                     self._launch(b)
         for b, work in self._pending:
-            work.wait()
+            if work is not None:
+                work.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         inv = 1.0 / self.world

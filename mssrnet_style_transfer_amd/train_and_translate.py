@@ -45,6 +45,22 @@ def fetch_dec_output_length(vocab_probs, cfg):
     return lens, ids
 
 
+def dec_output_length(vocab_probs, cfg):
+    """fetch_dec_output_length on the device: (lengths Long[B], argmax ids [steps, B]) with no host round trip --
+    first stop token + 1 (or seq_len), 'cut <= 1 -> seq_len', and the FIRST longest sentence forced to seq_len
+    (the reference's `if cut > best` scan keeps the first maximum, as torch.argmax does)."""
+    seq_len = vocab_probs.size(0)
+    ids = torch.argmax(vocab_probs, 2)
+    stop = ids == cfg.eos_idx
+    if cfg.sent_stop_aware:
+        stop = stop | (ids == cfg.dot_idx) | (ids == cfg.excl_idx) | (ids == cfg.qst_idx)
+    pos = torch.arange(1, seq_len + 1, device=ids.device).unsqueeze(1)
+    cut = torch.where(stop, pos, torch.full_like(pos, seq_len)).min(0).values
+    cut = torch.where(cut <= 1, torch.full_like(cut, seq_len), cut)
+    cut.scatter_(0, cut.argmax().view(1), seq_len)
+    return cut, ids
+
+
 def decode_batch_ori(model, cfg, src, enc_states, memory_bank, src_lengths, max_dec_steps=None):
     """Returns (vocab_probs [steps,B,V] fp32, seq_lens list, pred_ids [steps,B]).  The whole
     step loop runs inside the decode engine (decode_engine.soft_decode: one autograd node, one C

@@ -16,14 +16,32 @@ from torch.nn.utils import clip_grad_norm_
 
 from . import ops
 from .decode_engine import soft_decode
-from .train_and_translate import decode_batch_ori, fetch_dec_output_length, generator_probs
+from .train_and_translate import dec_output_length, generator_probs
 from .utils.misc import sequence_mask
 
 
 def cal_disc_loss(probs, labels):
-    """probs[i, labels[i]] as a [N] tensor (one gather instead of the reference's per-row loop)."""
-    idx = torch.as_tensor(labels, device=probs.device).view(-1, 1)
-    return probs.gather(1, idx).squeeze(1)
+    """probs[i, labels[i]] as a [N] tensor (one gather instead of the reference's per-row loop).  ``labels``:
+    a device tensor (no host round trip) or a Python list as in the reference."""
+    idx = labels if torch.is_tensor(labels) else torch.as_tensor(labels, device=probs.device)
+    return probs.gather(1, idx.view(-1, 1)).squeeze(1)
+
+
+def _to_device_async(t, like):
+    """Host tensor -> like's device and dtype without blocking the host (pinned staging + non_blocking copy):
+    a plain .to(device) of pageable memory waits for the stream."""
+    if not like.is_cuda:
+        return t.to(like)
+    return t.to(like.dtype).pin_memory().to(like.device, non_blocking=True)
+
+
+def _masked_penalty(g2d, mask, k, lamb):
+    """((||g_i|| - k)^2 over the rows where mask is set).mean() * lamb, as g2d[mask] would give it but without
+    boolean indexing (nonzero = a device sync in the middle of the phase)."""
+    sq = (g2d.float() ** 2).sum(1)
+    norm = torch.where(mask, sq, torch.ones_like(sq)).sqrt()
+    pen = torch.where(mask, (norm - k) ** 2, torch.zeros_like(norm))
+    return pen.sum() / mask.sum() * lamb
 
 
 def convert_sent_ids_to_onehot(sent_ids, vocab_size):
@@ -32,30 +50,32 @@ def convert_sent_ids_to_onehot(sent_ids, vocab_size):
     return oh.scatter_(1, sent_ids.reshape(-1, 1), 1).view(B, L, vocab_size)
 
 
-def penalize_gen_style_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.0, gp_norm_seq=True):
+def penalize_gen_style_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.0, gp_norm_seq=True, alpha=None):
     """real/fake [B, L, dim]; alpha is drawn from the CPU generator exactly as the reference does
-    (torch.rand(B,1,1).type_as(real), trainer_wgan_wh.py:1238)."""
-    alpha = torch.rand(real.size(0), 1, 1).to(real)
+    (torch.rand(B,1,1).type_as(real), trainer_wgan_wh.py:1238) unless the caller drew it already."""
+    alpha = _to_device_async(torch.rand(real.size(0), 1, 1) if alpha is None else alpha, real)
     inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
     with ops.second_order():
         err = cal_disc_loss(d_model(inter, lengths), labels)
     g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     if gp_norm_seq:
-        g = g.contiguous().view(-1, g.size(-1))[sequence_mask(lengths).contiguous().view(-1)]
+        return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
+                               sequence_mask(lengths, max_len=real.size(1)).contiguous().view(-1), k, lamb)
     return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
 
 
-def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.0, gp_norm_seq=True):
+def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.0, gp_norm_seq=True, alpha=None):
     """real/fake [B, T, V]; the critic takes [T, B, V] (trainer_wgan_wh.py:1283-1331)."""
     x_len = real.size(1)
-    alpha = torch.rand(real.size(0), 1, 1).to(real)
+    alpha = _to_device_async(torch.rand(real.size(0), 1, 1) if alpha is None else alpha, real)
     inter = (alpha * real + (1 - alpha) * fake).transpose(0, 1).detach().requires_grad_(True)
     with ops.second_order():
         err = cal_disc_loss(d_model(inter, lengths), labels)
     g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     g = g.transpose(0, 1)
     if gp_norm_seq:
-        g = g.contiguous().view(-1, g.size(-1))[sequence_mask(lengths, max_len=x_len).contiguous().view(-1)]
+        return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
+                               sequence_mask(lengths, max_len=x_len).contiguous().view(-1), k, lamb)
     return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
 
 
@@ -81,6 +101,7 @@ class Trainer:
         self.one = torch.ones([], device=dev)
         self.mone = -torch.ones([], device=dev)
         self.pad_tensor = torch.full((1, 1, 1), cfg.pad_idx, dtype=torch.long, device=dev)
+        self._label_table = None
 
     # ------------------------------------------------------------------ pieces
     def _gain(self, logits, mode):
@@ -101,8 +122,12 @@ class Trainer:
         src, src_lengths = batch.src, batch.src_lengths
         real_src = src[1:]
         real_len = src_lengths - 1
-        labels_list = [cfg.label_token_ids.index(t) for t in src[0, :, 0].tolist()]
-        labels = torch.tensor(labels_list, dtype=torch.long, device=src.device)
+        # style label = position of the sentence's label token in cfg.label_token_ids, looked up on the device
+        # (the reference walks a Python list, :389-400; a .tolist() here would drain the GPU queue every phase)
+        if self._label_table is None or self._label_table.device != src.device:
+            self._label_table = torch.tensor(cfg.label_token_ids, dtype=torch.long, device=src.device)
+        labels = (src[0, :, 0].unsqueeze(1) == self._label_table.unsqueeze(0)).long().argmax(1)
+        labels_list = labels            # consumers index with it (cal_disc_loss): the tensor serves
         vocab_target = torch.cat([batch.tgt[1:], self.pad_tensor.repeat(1, batch.tgt.size(1), 1)])
         return labels, labels_list, real_src, real_len, vocab_target
 
@@ -122,7 +147,8 @@ class Trainer:
 
     def cal_style_gap(self, real, gen, lengths):
         gap = ((real.float() - gen.float()) ** 2).sum(2).transpose(0, 1)
-        return gap[sequence_mask(lengths, max_len=real.size(0))].mean()
+        mask = sequence_mask(lengths, max_len=real.size(0))
+        return torch.where(mask, gap, torch.zeros_like(gap)).sum() / mask.sum()      # gap[mask].mean(), no sync
 
     def _gen_real_style_represents(self, real_src, real_len):
         with torch.no_grad():
@@ -143,9 +169,12 @@ class Trainer:
         return generator_probs(self.model, dec_out, self.cfg.dec_temperature, log=True)
 
     def _dynamic_decoding(self, real_src, real_len, style_rep, max_dec_steps):
+        """-> (probs [steps, B, V], lengths Long[B] on the device, argmax ids [steps, B]); no host sync."""
         enc_state, mem, _ = self._encode(real_src, real_len, style_rep)
-        probs, lens, ids = decode_batch_ori(self.model, self.cfg, real_src, enc_state, mem, real_len, max_dec_steps)
-        return probs, torch.tensor(lens, dtype=torch.long, device=real_len.device), ids
+        self.model.decoder.init_state(real_src, mem, enc_state)
+        probs = soft_decode(self.model, self.cfg, mem, real_len, max_dec_steps)
+        lens, ids = dec_output_length(probs, self.cfg)
+        return probs, lens, ids
 
     def _arm(self, *modules):
         """Start overlapping the gradient all-reduce of ``modules`` with their LAST backward."""
@@ -176,11 +205,19 @@ class Trainer:
         text_len = (real_len + 1).detach()
         if cfg.discr_sent_stop_aware:
             text_len = torch.ones_like(real_len) * vocab_target.size(0)
+        B = real_len.numel()
+        alpha_t, alpha_s = torch.rand(B, 1, 1), torch.rand(B, 1, 1)       # in the order the reference draws them
+        # The generator side is in eval mode: its style representation is deterministic, so the reference's two
+        # no_grad calls (:533 for the fake text, :571 for the fake style) are one here.
+        with torch.no_grad():
+            rep = self._gen_style_represents(labels, real_src, real_len)
+        real_rep_t = self._gen_real_style_represents(real_src, real_len).transpose(0, 1)
+        gen_rep_t = rep.transpose(0, 1)
+
         # text critic: real / fake / gradient penalty
         gain_t_real = cal_disc_loss(self._call_text_discriminator(vocab_target, text_len), labels_list).mean()
         gain_t_real.backward(self.mone)
         with torch.no_grad():
-            rep = self._gen_style_represents(labels, real_src, real_len)
             probs, _, _ = self._dynamic_decoding(real_src, real_len, rep, vocab_target.size(0))
         gain_t_fake = cal_disc_loss(self._call_text_discriminator(probs, text_len), labels_list).mean()
         gain_t_fake.backward(self.one)
@@ -188,20 +225,19 @@ class Trainer:
             probs_t = probs.transpose(0, 1)
             real_onehot = convert_sent_ids_to_onehot(vocab_target.transpose(0, 1).squeeze(2), cfg.vocab_size)
         t_gp = penalize_gen_text_grad(self._call_text_discriminator, real_onehot, probs_t, text_len, labels_list,
-                                      k=cfg.wgan_text_k, lamb=cfg.wgan_text_lamb, gp_norm_seq=cfg.use_gp_norm_seq)
+                                      k=cfg.wgan_text_k, lamb=cfg.wgan_text_lamb, gp_norm_seq=cfg.use_gp_norm_seq,
+                                      alpha=alpha_t)
         self._arm(self.text_discriminator)
         t_gp.backward()
-        # style critic
-        real_rep_t = self._gen_real_style_represents(real_src, real_len).transpose(0, 1)
+        # style critic (run on a helper thread / side stream during the decode it measured 2 % SLOWER: launches
+        # from two threads contend in the runtime and stretch the GPU-bound decode)
         gain_s_real = cal_disc_loss(self._call_style_discriminator(real_rep_t, real_len), labels_list).mean()
         gain_s_real.backward(self.mone)
-        with torch.no_grad():
-            gen_rep_t = self._gen_style_represents(labels, real_src, real_len).transpose(0, 1)
         gain_s_fake = cal_disc_loss(self._call_style_discriminator(gen_rep_t, real_len), labels_list).mean()
         gain_s_fake.backward(self.one)
         s_gp = penalize_gen_style_grad(self._call_style_discriminator, real_rep_t.float(), gen_rep_t.float(),
                                        real_len, labels_list, k=cfg.wgan_style_k, lamb=cfg.wgan_style_lamb,
-                                       gp_norm_seq=cfg.use_gp_norm_seq)
+                                       gp_norm_seq=cfg.use_gp_norm_seq, alpha=alpha_s)
         self._arm(self.style_discriminator)
         s_gp.backward()
         self._finish((self.style_discriminator, self.text_discriminator),
@@ -222,7 +258,7 @@ class Trainer:
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
         tgt_len, B = vocab_target.size(0), vocab_target.size(1)
         desired = 1 - labels
-        desired_list = desired.tolist()
+        desired_list = desired
         max_dec_steps = tgt_len + cfg.max_extra_dec_steps
         rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1),
                                              real_len.repeat(3))
@@ -232,8 +268,7 @@ class Trainer:
         self.model.decoder.init_state(src2, mem, enc_state)
         probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
         probs, sprobs = probs_all[:, :B], probs_all[:tgt_len, B:]
-        seq_lens_list, _ = fetch_dec_output_length(probs, cfg)
-        seq_lens = torch.tensor(seq_lens_list, dtype=torch.long, device=real_len.device)
+        seq_lens, _ = dec_output_length(probs, cfg)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
         gain_t = cal_disc_loss(self._call_text_discriminator(probs, lens), desired_list).mean()
         with torch.no_grad():
@@ -260,7 +295,7 @@ class Trainer:
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
         tgt_len, B = vocab_target.size(0), vocab_target.size(1)
         desired = 1 - labels                                   # num_styles == 2 (train_and_translate.py:72-73)
-        desired_list = desired.tolist()
+        desired_list = desired
         max_dec_steps = tgt_len + cfg.max_extra_dec_steps
         log = {}
         rep = self._gen_style_represents(desired, real_src, real_len)
@@ -331,8 +366,7 @@ class Trainer:
         if not cfg.without_stl_penalty:
             l_gap = self.cal_style_gap(real_rep, rep_src, real_len)
             total = total + cfg.alpha_style_gap * l_gap
-        clens_list, _ = fetch_dec_output_length(cprobs, cfg)
-        clens = torch.tensor(clens_list, dtype=torch.long, device=real_len.device)
+        clens, _ = dec_output_length(cprobs, cfg)
         t_logits = self.classifier(cprobs, clens)
         l_t = F.nll_loss(F.log_softmax(t_logits, -1), desired)
         total = total + cfg.cls_loss_ratio * l_t

@@ -75,3 +75,28 @@ def test_length_rule_matches_oracle():
             b, ib = oracle_rule(probs, c)
             assert a == b and torch.equal(ia, ib)
             assert max(a) == 9
+
+
+def test_device_length_rule_matches_host_rule():
+    """dec_output_length (tensor ops, no host round trip) against fetch_dec_output_length (the reference's Python
+    scan, onmt/train_and_translate.py:289-326) on random and edge-case id tables."""
+    import torch
+    from mssrnet_style_transfer_amd.config import MSSRConfig
+    from mssrnet_style_transfer_amd.train_and_translate import dec_output_length, fetch_dec_output_length
+    g = torch.Generator().manual_seed(5)
+    for aware in (True, False):
+        cfg = MSSRConfig.small(sent_stop_aware=aware)
+        V = cfg.vocab_size
+        for T, B in ((1, 3), (6, 1), (9, 17), (28, 80)):
+            for trial in range(6):
+                ids = torch.randint(9, V, (T, B), generator=g)
+                stops = torch.tensor([cfg.eos_idx, cfg.dot_idx, cfg.excl_idx, cfg.qst_idx])
+                put = torch.rand(T, B, generator=g) < (0.0, 0.05, 0.2, 0.5, 1.0, 0.1)[trial]
+                ids = torch.where(put, stops[torch.randint(0, 4, (T, B), generator=g)], ids)
+                if trial == 5:
+                    ids[0] = cfg.eos_idx                  # a stop in the very first position: 'cut <= 1' rule
+                probs = torch.nn.functional.one_hot(ids, V).float()
+                want, want_ids = fetch_dec_output_length(probs, cfg)
+                got, got_ids = dec_output_length(probs, cfg)
+                assert got.tolist() == want, (aware, T, B, trial)
+                assert torch.equal(got_ids, want_ids)

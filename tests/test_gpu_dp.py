@@ -39,6 +39,8 @@ def _grads(nets, names):
 
 
 def _worker(rank, world, port, out):
+    import faulthandler
+    faulthandler.dump_traceback_later(90, exit=True)        # a stuck rank names its stack instead of hanging the run
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,6 +57,7 @@ def _worker(rank, world, port, out):
     res["G"] = _grads(nets, ("model", "style_generator"))
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
     dist.destroy_process_group()
+    faulthandler.cancel_dump_traceback_later()
 
 
 def test_data_parallel_phases_match_mean_of_single_process_gradients(tmp_path):
