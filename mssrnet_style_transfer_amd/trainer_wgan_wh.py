@@ -10,6 +10,8 @@ scalars are returned as a dict instead of going to InfoLogger / TensorBoard.
 Data parallelism: ``grad_sync`` (see parallel.py) is called once per optimizer step, after the
 last backward of the phase and before clipping, with the networks that are about to step.
 """
+from collections.abc import Mapping
+
 import torch
 import torch.nn.functional as F
 from torch.nn.utils import clip_grad_norm_
@@ -77,6 +79,37 @@ def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.
         return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
                                sequence_mask(lengths, max_len=x_len).contiguous().view(-1), k, lamb)
     return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
+
+
+class PhaseLog(Mapping):
+    """The logged scalars of one phase, read from the device on FIRST ACCESS.  The reference calls .item() on
+    every scalar every step (InfoLogger, trainer_wgan_wh.py:275-316), which drains the GPU queue at the end of
+    each phase; a training loop that reports every N steps only pays for the steps it looks at, and the host
+    starts the next phase while the GPU finishes this one."""
+
+    def __init__(self, names, values, derive=None):
+        self._names, self._dev, self._derive, self._d = list(names), torch.stack(
+            [v.detach().float() for v in values]), derive, None
+
+    def _get(self):
+        if self._d is None:
+            d = dict(zip(self._names, self._dev.tolist()))
+            if self._derive is not None:
+                d.update(self._derive(d))
+            self._d, self._dev = d, None
+        return self._d
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __len__(self):
+        return len(self._get())
+
+    def __repr__(self):
+        return "PhaseLog(%r)" % (self._get(),)
 
 
 class Trainer:
@@ -242,9 +275,10 @@ class Trainer:
         s_gp.backward()
         self._finish((self.style_discriminator, self.text_discriminator),
                      (self.style_discriminator_optim, self.text_discriminator_optim))
-        v = torch.stack([gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp]).tolist()   # one sync
-        return dict(TR_gain=v[0], TF_gain=v[1], T_gp=v[2], T_cost=v[1] - v[0] + v[2], T_Wgap=v[0] - v[1],
-                    SR_gain=v[3], SF_gain=v[4], S_gp=v[5], S_cost=v[4] - v[3] + v[5], S_Wgap=v[3] - v[4])
+        return PhaseLog(("TR_gain", "TF_gain", "T_gp", "SR_gain", "SF_gain", "S_gp"),
+                        (gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp),
+                        lambda d: dict(T_cost=d["TF_gain"] - d["TR_gain"] + d["T_gp"], T_Wgap=d["TR_gain"] - d["TF_gain"],
+                                       S_cost=d["SF_gain"] - d["SR_gain"] + d["S_gp"], S_Wgap=d["SR_gain"] - d["SF_gain"]))
 
     def _train_generator_batched(self, batch):
         """train_generator with its independent pieces batched (cfg.batch_generator_phase): the reference
@@ -279,8 +313,7 @@ class Trainer:
         self._arm(self.style_generator, self.model)
         total.backward()
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
-        v = torch.stack([t.detach().float() for t in (gain_t, acc, gain_s, vl)]).tolist()
-        return dict(AT_gain=v[0], AT_acc=v[1], AS_gain=v[2], T_selfstyle_vloss=v[3])
+        return PhaseLog(("AT_gain", "AT_acc", "AS_gain", "T_selfstyle_vloss"), (gain_t, acc, gain_s, vl))
 
     def train_generator(self, batch):
         cfg = self.cfg
@@ -297,7 +330,6 @@ class Trainer:
         desired = 1 - labels                                   # num_styles == 2 (train_and_translate.py:72-73)
         desired_list = desired
         max_dec_steps = tgt_len + cfg.max_extra_dec_steps
-        log = {}
         rep = self._gen_style_represents(desired, real_src, real_len)
         probs, seq_lens, _ = self._dynamic_decoding(real_src, real_len, rep, max_dec_steps)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
@@ -321,11 +353,8 @@ class Trainer:
             vl.backward()
             vals.append(vl)
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
-        v = torch.stack([t.detach().float() for t in vals]).tolist()
-        log.update(AT_gain=v[0], AT_acc=v[1], AS_gain=v[2])
-        if cfg.ap_gen_self_style_text:
-            log.update(T_selfstyle_vloss=v[3])
-        return log
+        names = ["AT_gain", "AT_acc", "AS_gain"] + (["T_selfstyle_vloss"] if cfg.ap_gen_self_style_text else [])
+        return PhaseLog(names, vals)
 
     def _train_reconstruct_batched(self, batch):
         """train_reconstruct with its independent pieces batched (cfg.batch_generator_phase), as in
@@ -379,7 +408,7 @@ class Trainer:
         self._arm(self.style_generator, self.model)
         total.backward()
         self._finish((self.style_generator, self.model), [self.style_generator_optim, self.model_optim], clip=False)
-        return dict(zip(names, torch.stack([t.detach().float() for t in vals]).tolist()))
+        return PhaseLog(names, vals)
 
     def train_reconstruct(self, batch):
         cfg = self.cfg
@@ -432,7 +461,7 @@ class Trainer:
         if cfg.use_cls_feedback or not cfg.without_stl_penalty:
             optims.insert(0, self.style_generator_optim)
         self._finish((self.style_generator, self.model), optims, clip=False)
-        return dict(zip(names, torch.stack([t.detach().float() for t in vals]).tolist()))
+        return PhaseLog(names, vals)
 
     def init_launch(self, batch):
         self.style_generator.train()
@@ -450,8 +479,7 @@ class Trainer:
         self._arm(self.model)
         l_v.backward()
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
-        v = torch.stack([l_style.detach(), l_v.detach()]).tolist()
-        return dict(INIT_SL=v[0], INIT_VL=v[1])
+        return PhaseLog(("INIT_SL", "INIT_VL"), (l_style, l_v))
 
 
 def teacher_step_loss(classifier, batch, cfg):
