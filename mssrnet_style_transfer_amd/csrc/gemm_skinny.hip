@@ -24,12 +24,13 @@ namespace mssr {
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int SK_THREADS = 256;
-constexpr int SK_GROUP = 4;          // k-steps (of 32) in flight per wave
+// k-steps (of 32) a wave keeps in flight: template parameter G = 4, 8 or 12, the smallest that covers the wave's
+// share of K in ONE batch of loads (K = 512 -> 4, 1024 -> 8, 1536 -> 12; one memory round trip instead of 2-3)
 constexpr int SK_MAX_STEPS = 64;     // k-steps per block without split-K (K <= 2048)
 constexpr int SK_MAX_M = 8192;       // above this the general LDS-tiled kernel (operand reuse) takes over
 
 // F = fragments per tile edge: F = 1 -> 16x16 tile (M <= 128), F = 2 -> 32x32 tile (larger M)
-template <typename TO, bool LN, int F>
+template <typename TO, bool LN, int F, int SK_GROUP>
 __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs p) {
     constexpr int TS = 16 * F;                 // tile edge
     constexpr int TE = TS * TS;                // tile elements
@@ -216,16 +217,33 @@ int gemm_skinny_tile(int64_t m, int64_t n, int64_t k) {
     return (m <= f1_max_m && blocks16 <= f1_max_blocks) ? 16 : 32;
 }
 
+// in-flight group for a problem: the wave's k-steps, rounded up to 4 / 8 / 12 (32x32 tiles hold 4x the fragments
+// per step, so they stay at 4)
+static int skinny_group(const GemmArgs& a, int tile) {
+    if (tile != 16) return 4;
+    const int64_t per_wave = ((a.k / 32 + a.ksplit - 1) / a.ksplit + 3) / 4;
+    return per_wave <= 4 ? 4 : per_wave <= 8 ? 8 : per_wave <= 12 ? 12 : 4;
+}
+
+template <typename TO, bool LN, int F>
+static void skinny_launch_g(const GemmArgs& a, const dim3 grid, int group, hipStream_t s) {
+    if (group == 8) klaunch(gemm_skinny_kernel<TO, LN, F, 8>, grid, dim3(SK_THREADS), 0, s, a);
+    else if (group == 12) klaunch(gemm_skinny_kernel<TO, LN, F, 12>, grid, dim3(SK_THREADS), 0, s, a);
+    else klaunch(gemm_skinny_kernel<TO, LN, F, 4>, grid, dim3(SK_THREADS), 0, s, a);
+}
+
 template <typename TO>
 static void skinny_launch(const GemmArgs& a, hipStream_t s) {
-    if (gemm_skinny_tile(a.m, a.n, a.k) == 16) {
+    const int tile = gemm_skinny_tile(a.m, a.n, a.k);
+    if (tile == 16) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
-        if (a.ln_colsum) klaunch(gemm_skinny_kernel<TO, true, 1>, grid, dim3(SK_THREADS), 0, s, a);
-        else klaunch(gemm_skinny_kernel<TO, false, 1>, grid, dim3(SK_THREADS), 0, s, a);
+        const int g = skinny_group(a, tile);
+        if (a.ln_colsum) skinny_launch_g<TO, true, 1>(a, grid, g, s);
+        else skinny_launch_g<TO, false, 1>(a, grid, g, s);
     } else {
         const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
-        if (a.ln_colsum) klaunch(gemm_skinny_kernel<TO, true, 2>, grid, dim3(SK_THREADS), 0, s, a);
-        else klaunch(gemm_skinny_kernel<TO, false, 2>, grid, dim3(SK_THREADS), 0, s, a);
+        if (a.ln_colsum) klaunch(gemm_skinny_kernel<TO, true, 2, 4>, grid, dim3(SK_THREADS), 0, s, a);
+        else klaunch(gemm_skinny_kernel<TO, false, 2, 4>, grid, dim3(SK_THREADS), 0, s, a);
     }
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;

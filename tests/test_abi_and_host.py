@@ -100,3 +100,14 @@ def test_device_length_rule_matches_host_rule():
                 got, got_ids = dec_output_length(probs, cfg)
                 assert got.tolist() == want, (aware, T, B, trial)
                 assert torch.equal(got_ids, want_ids)
+
+
+def test_phase_log_reads_lazily_and_behaves_like_a_dict():
+    import torch
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import PhaseLog
+    a, b = torch.tensor(1.5, requires_grad=True), torch.tensor(0.25)
+    log = PhaseLog(("x", "y"), (a * 2, b), lambda d: dict(z=d["x"] - d["y"]))
+    assert log._d is None                      # nothing read yet
+    assert log["x"] == 3.0 and log["z"] == 2.75
+    assert dict(log) == {"x": 3.0, "y": 0.25, "z": 2.75} and len(log) == 3
+    assert {**log, "k": 1}["y"] == 0.25
