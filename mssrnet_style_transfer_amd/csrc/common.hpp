@@ -106,13 +106,24 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_read(v, 0), lane_read(v, 16)), fmaxf(lane_read(v, 32), lane_read(v, 48)));
 }
 
-// counter-based RNG for dropout: one 32-bit hash per element index (splitmix-style finaliser)
+// counter-based RNG for dropout: one 32-bit hash per element index.  32-bit arithmetic only (two multiplies:
+// the "lowbias32" finaliser over index ^ seed mix): the 64-bit splitmix it replaces cost ~400 cycles per wave
+// and element on CDNA (64-bit multiplies are sequences of quarter-rate 32-bit ones), which made the mask the
+// most expensive part of every kernel that replays dropout.  The seed mix is uniform (scalar unit).
+__device__ __forceinline__ uint32_t mix_u32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x;
+}
 __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
-    uint64_t z = seed + idx * 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z = z ^ (z >> 31);
-    return (uint32_t)(z >> 32);
+    // seeds of neighbouring sites / steps differ in a few bits: mix them first (uniform, scalar unit), so that two
+    // sites' index spaces are xor-shifted apart by a full-width random constant
+    const uint32_t s = mix_u32((uint32_t)seed) ^ mix_u32((uint32_t)(seed >> 32) + 0x9E3779B9u);
+    const uint32_t hi = (uint32_t)(idx >> 32);
+    return mix_u32((uint32_t)idx ^ s ^ ((hi << 16) | (hi >> 16)));
 }
 
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
