@@ -458,12 +458,19 @@ class _Softmax(Function):
                                           scale, int(log_mode), L.dt(xc), L.dt(y), L.stream()), "softmax_fwd")
         ctx.save_for_backward(y)
         ctx.scale, ctx.log_mode, ctx.in_dtype = scale, log_mode, x.dtype
+        ctx.mask = None if mask is None else (mask != 0)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         y, = ctx.saved_tensors
-        return _SoftmaxBwd.apply(y, dy, ctx.scale, ctx.log_mode, ctx.in_dtype), None, None, None, None
+        dx = _SoftmaxBwd.apply(y, dy, ctx.scale, ctx.log_mode, ctx.in_dtype)
+        if ctx.mask is not None:
+            # masked_fill blocks the gradient of the entries it overwrites (multi_headed_attn.py:197-199).  Where a
+            # row keeps some key, masked entries have y = 0 and so dx = 0 already; a row with EVERY key masked is
+            # uniform and the softmax formula alone would hand its scores a gradient they never see in the reference
+            dx = dx.masked_fill(ctx.mask.unsqueeze(1), 0)
+        return dx, None, None, None, None
 
 
 class _SoftmaxBwd(Function):

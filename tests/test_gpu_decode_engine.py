@@ -170,3 +170,19 @@ def test_engine_long_sequences_fp32(ops):
     assert_close(ge_mem, gm_mem, 5e-4, "d memory_bank")
     dec_keys = [k for k in gm if k.startswith("decoder.") or k.startswith("generator.")]
     assert_grads({k: ge[k] for k in dec_keys}, {k: gm[k] for k in dec_keys}, 5e-4, "decoder")
+
+
+@pytest.mark.parametrize("B,Ls,steps", [(1, 1, 1), (2, 1, 3), (1, 3, 2), (17, 2, 1)])
+def test_engine_smallest_shapes_fp32(ops, B, Ls, steps):
+    """One sentence, one source word, one step: the corners of the engine's range against the modular path."""
+    cfg = MSSRConfig.small()
+    model, src, lens, mem = setup(cfg, B, Ls, seed=20 + B + Ls)
+    model.train()
+    w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
+    pe, ge_mem, ge, le, ie = run("decode_batch_ori", model, cfg, src, lens, mem, steps, w)
+    pm, gm_mem, gm, lm, im = run("decode_batch_modular", model, cfg, src, lens, mem, steps, w)
+    assert_close(pe, pm, 1e-4, "probs")
+    assert le == lm and torch.equal(ie, im)
+    assert_close(ge_mem, gm_mem, 2e-4, "d memory_bank", floor=1e-9)
+    dec_keys = [k for k in gm if k.startswith("decoder.") or k.startswith("generator.")]
+    assert_grads({k: ge[k] for k in dec_keys}, {k: gm[k] for k in dec_keys}, 2e-4, "decoder")

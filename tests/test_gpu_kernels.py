@@ -370,6 +370,38 @@ def test_fused_attention_dropout_and_limits(ops):
     assert_close(o_big, ref, 1e-4, "beyond the fused limits")
 
 
+@pytest.mark.parametrize("B,H,Lq,Lk,dh", [(1, 1, 1, 1, 8), (2, 3, 1, 64, 16), (2, 2, 64, 64, 64), (3, 2, 5, 7, 32),
+                                          (4, 8, 17, 17, 64)])
+def test_fused_attention_edge_shapes_and_masked_rows(ops, B, H, Lq, Lk, dh):
+    """Fused attention at the corners of its range (one key, one query, the 64 x 64 x 64 maximum, ragged pad masks)
+    and with a sentence whose keys are ALL masked: the finite -1e18 fill makes that row a uniform distribution, not
+    NaN (onmt/modules/multi_headed_attn.py:195-202).  Values, probabilities and gradients against plain torch."""
+    torch.manual_seed(B * 1000 + Lk)
+    q, k, v = (torch.randn(B, n, H * dh, device="cuda").view(B, n, H, dh).transpose(1, 2).detach().requires_grad_(True)
+               for n in (Lq, Lk, Lk))
+    lens = torch.randint(1, Lk + 1, (B,), device="cuda")
+    lens[0] = Lk
+    mask = torch.arange(Lk, device="cuda").unsqueeze(0) >= lens.unsqueeze(1)            # True = masked
+    if B > 1:
+        mask[B - 1] = True                                                              # a fully masked sentence
+    mask3 = mask.unsqueeze(1)
+    w = torch.randn(B, H, Lq, dh, device="cuda")
+    out, probs = ops.attention(q, k, v, mask3, 0.0, False)
+    g = torch.autograd.grad((out * w).sum(), (q, k, v))
+    qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    sc = (qr / dh ** 0.5) @ kr.transpose(-1, -2)
+    pr = torch.softmax(sc.masked_fill(mask3.unsqueeze(1), -1e18), -1)
+    ref = pr @ vr
+    gr = torch.autograd.grad((ref * w.double()).sum(), (qr, kr, vr))
+    assert torch.isfinite(out).all() and torch.isfinite(probs).all()
+    assert_close(out, ref.float(), 1e-4, "out")
+    assert_close(probs, pr.float(), 1e-4, "probs")
+    if B > 1:
+        assert_close(probs[B - 1], torch.full_like(probs[B - 1], 1.0 / Lk), 1e-5, "fully masked row is uniform")
+    for name, a, b in zip("qkv", g, gr):
+        assert_close(a, b.float(), 2e-4, "d" + name, floor=1e-6)
+
+
 def test_mha_cached(ops, golden_ops):
     from mssrnet_style_transfer_amd.modules.multi_headed_attn import MultiHeadedAttention
     c = golden_ops["mha_cached"]
