@@ -26,7 +26,7 @@ def setup(cfg, B, Ls, seed=0):
     from mssrnet_style_transfer_amd import style_generator_builder as SB
     torch.manual_seed(seed)
     model = SB.build_main_model(cfg).cuda()
-    lens = torch.randint(2, Ls + 1, (B,))
+    lens = torch.randint(min(2, Ls), Ls + 1, (B,))
     lens[0] = Ls
     lens = lens.sort(descending=True).values.cuda()
     src = torch.randint(9, cfg.vocab_size, (Ls, B, 1)).cuda()
