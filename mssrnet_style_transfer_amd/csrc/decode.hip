@@ -18,9 +18,9 @@
 
 namespace mssr {
 
-constexpr int AT_MAXK = 512; 
-constexpr int AT_PF = 16;         // value / key rows prefetched into registers per lane (Yelp lengths: <= 16-28 keys)
-constexpr int MAX_CHUNKS = 8;      // concurrent batch chunks (streams) of one decode   // keys per (b, h) the step-attention kernels handle
+constexpr int AT_MAXK = 512;       // keys per (sentence, head) the step-attention kernels handle
+constexpr int AT_PF = 16;          // one-row-per-lane kernels: value / key rows prefetched into registers per lane
+constexpr int MAX_CHUNKS = 8;      // concurrent batch chunks (streams) of one decode
 
 // ------------------------------------------------------------------ single-query attention
 // One wave64 per (batch, head).  q [dh], keys/values addressed with strides, optional pad mask.

@@ -256,7 +256,11 @@ int gemm_skinny_ksplit(int64_t k) { return (int)((k / 32 + SK_MAX_STEPS - 1) / S
 
 bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch) {
     if (in_dtype != MSSR_BF16 || batch != 1) return false;
-    if (a.m < 1 || a.m > SK_MAX_M || (a.m + 31) / 32 > 65535 || a.k < 32 || a.k % 32 != 0) return false;
+    static const int64_t max_m = [] {
+        const char* e = getenv("MSSR_SKINNY_MAXM");
+        return e ? (int64_t)atoll(e) : (int64_t)SK_MAX_M;
+    }();
+    if (a.m < 1 || a.m > (a.ln_colsum ? (int64_t)SK_MAX_M : max_m) || (a.m + 31) / 32 > 65535 || a.k < 32 || a.k % 32 != 0) return false;
     if (a.a_cs != 1 || a.b_rs != 1) return false;                       // both operands k-contiguous
     if (a.a_rs % 8 != 0 || a.b_cs % 8 != 0 || !aligned(a.a, 16) || !aligned(a.b, 16)) return false;
     const int ks = gemm_skinny_ksplit(a.k);

@@ -160,7 +160,7 @@ class Trainer:
         if self._label_table is None or self._label_table.device != src.device:
             self._label_table = torch.tensor(cfg.label_token_ids, dtype=torch.long, device=src.device)
         labels = (src[0, :, 0].unsqueeze(1) == self._label_table.unsqueeze(0)).long().argmax(1)
-        labels_list = labels            # consumers index with it (cal_disc_loss): the tensor serves
+        labels_list = labels            # the reference's Python list; cal_disc_loss gathers with the tensor itself
         vocab_target = torch.cat([batch.tgt[1:], self.pad_tensor.repeat(1, batch.tgt.size(1), 1)])
         return labels, labels_list, real_src, real_len, vocab_target
 
