@@ -243,7 +243,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
 // of K, of V (and, in the backward, of the later steps' q / dctx rows and slab coefficients) is known at kernel
 // start, so for up to 64 bf16 rows the whole kernel exposes ONE memory round trip; the one-row-per-lane kernels
 // above issue Lk dependent 2-byte loads in their lane <-> feature phases (measured at 140 keys: 55 / 140 us).
-constexpr int AT_NL = 8;
+// AT_NL load instructions per chunk: template parameter, 4 when every operand has at most 4 x (rows per
+// instruction) rows (Yelp lengths: <= 28 keys / steps at 8 rows per instruction), else 8
 
 template <typename T> struct Row16;
 template <> struct Row16<bf16> {
@@ -313,7 +314,7 @@ __device__ __forceinline__ void cross_group_sum(float (&a)[N]) {
 
 // rows t0 + i*RPL + r (clamped to n_rows - 1) of a [n_rows, dh] operand with row stride `rs`; `base` already
 // points at this lane's 16-byte column group
-template <typename T>
+template <typename T, int AT_NL>
 __device__ __forceinline__ void load_chunk(typename Row16<T>::V (&dst)[AT_NL], const T* base, int64_t rs, int t0, int r,
                                            int RPL, int n_rows) {
 #pragma unroll
@@ -324,7 +325,15 @@ __device__ __forceinline__ void load_chunk(typename Row16<T>::V (&dst)[AT_NL], c
     }
 }
 
-template <typename T, int LS>
+// Every wave of these kernels owns its (sentence, head) slice and its own LDS rows: lanes exchange values through
+// LDS inside ONE wave only, whose DS instructions execute in program order.  A compiler-level fence is all that is
+// needed between a phase's writes and the next phase's reads; a block barrier would couple four unrelated waves.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int LS, int AT_NL>
 __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
@@ -345,8 +354,8 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     const T* vp = v + (int64_t)b * kv_bs + h * dh + c * E;
     float* s = sc[wave];
     V k0[AT_NL], v0[AT_NL];
-    load_chunk<T>(k0, kp, kv_ts, 0, r, RPL, Lk);
-    load_chunk<T>(v0, vp, kv_ts, 0, r, RPL, Lk);
+    load_chunk<T, AT_NL>(k0, kp, kv_ts, 0, r, RPL, Lk);
+    load_chunk<T, AT_NL>(v0, vp, kv_ts, 0, r, RPL, Lk);
     const V qf = R::load(qp);
     const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
 
@@ -362,10 +371,10 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     scores(k0, 0);
     for (int t0 = RC; t0 < Lk; t0 += RC) {
         V kt[AT_NL];
-        load_chunk<T>(kt, kp, kv_ts, t0, r, RPL, Lk);
+        load_chunk<T, AT_NL>(kt, kp, kv_ts, t0, r, RPL, Lk);
         scores(kt, t0);
     }
-    __syncthreads();
+    wave_lds_sync();
     float mx = -INFINITY;
     for (int t = lane; t < Lk; t += 64) {
         float a = s[t];
@@ -390,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
         if (p_drop > 0.f) p = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? p * keep_scale : 0.f;
         s[t] = p;
     }
-    __syncthreads();
+    wave_lds_sync();
     float acc[E];
 #pragma unroll
     for (int e = 0; e < E; ++e) acc[e] = 0.f;
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     ctxacc(v0, 0);
     for (int t0 = RC; t0 < Lk; t0 += RC) {
         V vt[AT_NL];
-        load_chunk<T>(vt, vp, kv_ts, t0, r, RPL, Lk);
+        load_chunk<T, AT_NL>(vt, vp, kv_ts, t0, r, RPL, Lk);
         ctxacc(vt, t0);
     }
     cross_group_sum<LS, E>(acc);
@@ -416,7 +425,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
 
 // Backward (see attn_step_bwd_kernel for the math and the gather form): chunk 0 of K, V, of the later steps'
 // q / dctx rows and the slab coefficients are all requested before the first use.
-template <typename T, int LS>
+template <typename T, int LS, int AT_NL>
 __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
@@ -448,15 +457,15 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     const int n_rows = gather ? n_steps - step : 0;      // this step and the later ones
 
     V k0[AT_NL], v0[AT_NL], q0[AT_NL], d0[AT_NL];
-    load_chunk<T>(k0, kp, kv_ts, 0, r, RPL, Lk);
-    load_chunk<T>(v0, vp, kv_ts, 0, r, RPL, Lk);
+    load_chunk<T, AT_NL>(k0, kp, kv_ts, 0, r, RPL, Lk);
+    load_chunk<T, AT_NL>(v0, vp, kv_ts, 0, r, RPL, Lk);
     const V qf = R::load(qp);
     const V df = R::load(dcp);
     const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
     float ck0 = 0.f, cv0 = 0.f;
     if (gather) {
-        load_chunk<T>(q0, qp, q_ss, 0, r, RPL, n_rows);
-        load_chunk<T>(d0, dcp, dctx_ss, 0, r, RPL, n_rows);
+        load_chunk<T, AT_NL>(q0, qp, q_ss, 0, r, RPL, n_rows);
+        load_chunk<T, AT_NL>(d0, dcp, dctx_ss, 0, r, RPL, n_rows);
         const int i = lane >= 1 && lane < n_rows ? lane : (n_rows > 1 ? 1 : 0);
         if (n_rows > 1) {                       // slabs of the later steps exist (written by earlier launches)
             ck0 = dso[(int64_t)i * slab_ss + step];
@@ -480,11 +489,11 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     phase_a(k0, v0, 0);
     for (int t0 = RC; t0 < Lk; t0 += RC) {
         V kt[AT_NL], vt[AT_NL];
-        load_chunk<T>(kt, kp, kv_ts, t0, r, RPL, Lk);
-        load_chunk<T>(vt, vp, kv_ts, t0, r, RPL, Lk);
+        load_chunk<T, AT_NL>(kt, kp, kv_ts, t0, r, RPL, Lk);
+        load_chunk<T, AT_NL>(vt, vp, kv_ts, t0, r, RPL, Lk);
         phase_a(kt, vt, t0);
     }
-    __syncthreads();
+    wave_lds_sync();
     float mx = -INFINITY;
     for (int t = lane; t < Lk; t += 64) {
         float a = s[t];
@@ -524,10 +533,10 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         s[t] = ds;
         if (active) dso[t] = ds;
     }
-    __syncthreads();
+    wave_lds_sync();
     const float ds_own = gather ? s[step] : 0.f;
     const float pd_own = gather ? pdv[step] : 0.f;
-    __syncthreads();
+    wave_lds_sync();
     if (gather) {                                // coefficient of row `step` in the slab of step step + i
         if (lane == 0) {
             dpv[0] = ds_own;
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
             pdv[i] = pdo[(int64_t)i * slab_ss + step];
         }
     }
-    __syncthreads();
+    wave_lds_sync();
     // dq = sum_t ds_t K[t]
     float acc[E];
 #pragma unroll
@@ -559,7 +568,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     dqacc(k0, 0);
     for (int t0 = RC; t0 < Lk; t0 += RC) {
         V kt[AT_NL];
-        load_chunk<T>(kt, kp, kv_ts, t0, r, RPL, Lk);
+        load_chunk<T, AT_NL>(kt, kp, kv_ts, t0, r, RPL, Lk);
         dqacc(kt, t0);
     }
     cross_group_sum<LS, E>(acc);
@@ -586,8 +595,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     gacc(q0, d0, 0);
     for (int t0 = RC; t0 < n_rows; t0 += RC) {
         V qt[AT_NL], dt[AT_NL];
-        load_chunk<T>(qt, qp, q_ss, t0, r, RPL, n_rows);
-        load_chunk<T>(dt, dcp, dctx_ss, t0, r, RPL, n_rows);
+        load_chunk<T, AT_NL>(qt, qp, q_ss, t0, r, RPL, n_rows);
+        load_chunk<T, AT_NL>(dt, dcp, dctx_ss, t0, r, RPL, n_rows);
         gacc(qt, dt, t0);
     }
     cross_group_sum<LS, E>(gk);
@@ -721,10 +730,15 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     const int dh = p->d / p->heads;
     const int bh = c.Bc * p->heads;
     const int sh = tiled_shift<T>(dh, {q, k, v, ctx}, {q_bs, kv_bs, kv_ts, ctx_bs});
-#define MSSR_FWD_TILED(LS)                                                                                          \
-    attn_step_fwd_tiled_kernel<T, LS><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                        \
+#define MSSR_FWD_TILED_N(LS, NL)                                                                                    \
+    attn_step_fwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh, \
         Lk, 1.0f / sqrtf((float)dh), p_drop, seed)
+#define MSSR_FWD_TILED(LS)                            \
+    do {                                              \
+        if (Lk <= 4 * (64 >> LS)) MSSR_FWD_TILED_N(LS, 4); \
+        else MSSR_FWD_TILED_N(LS, 8);                 \
+    } while (0)
     switch (sh) {
         case 1: MSSR_FWD_TILED(1); return;
         case 2: MSSR_FWD_TILED(2); return;
@@ -733,6 +747,7 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
         default: break;
     }
 #undef MSSR_FWD_TILED
+#undef MSSR_FWD_TILED_N
     attn_step_fwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh,
         Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
@@ -749,11 +764,17 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     const int bh = c.Bc * p->heads;
     const int sh = tiled_shift<T>(dh, {q, k, v, dctx, dq, dk_out, dv_out},
                                   {q_bs, kv_bs, kv_ts, dctx_bs, dq_bs, q_ss, dctx_ss, out_bs});
-#define MSSR_BWD_TILED(LS)                                                                                          \
-    attn_step_bwd_tiled_kernel<T, LS><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                        \
+#define MSSR_BWD_TILED_N(LS, NL)                                                                                    \
+    attn_step_bwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,    \
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,  \
         c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed)
+#define MSSR_BWD_TILED(LS)                                                              \
+    do {                                                                                \
+        const int need = gather && p->T - step > Lk ? p->T - step : Lk;                 \
+        if (need <= 4 * (64 >> LS)) MSSR_BWD_TILED_N(LS, 4);                            \
+        else MSSR_BWD_TILED_N(LS, 8);                                                   \
+    } while (0)
     switch (sh) {
         case 1: MSSR_BWD_TILED(1); return;
         case 2: MSSR_BWD_TILED(2); return;
@@ -762,6 +783,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
         default: break;
     }
 #undef MSSR_BWD_TILED
+#undef MSSR_BWD_TILED_N
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,
