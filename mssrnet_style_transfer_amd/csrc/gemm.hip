@@ -7,6 +7,7 @@
 // Operands may be k-contiguous ("NT" weights, activations) or row-contiguous (transposed
 // views: dW = dY^T X, P V, ...): the loader picks the coalesced direction per operand.
 #include "gemm_common.hpp"
+#include <stdlib.h>
 
 namespace mssr {
 
@@ -169,10 +170,31 @@ static inline bool use_tile64(int64_t m, int64_t n, int64_t batch) {
     const int64_t tiles64 = ((m + 63) / 64) * ((n + 63) / 64) * batch;
     return tiles64 >= 192 && m > 32 && n > 32;
 }
+// block tile for a problem: 128x128 (4x the MFMA work per LDS barrier of the 64x64 tile) once there are plenty of
+// tiles for the 256 CUs, else 64x64, else 32x32
+static inline int pick_tile(int64_t m, int64_t n, int64_t batch) {
+    static const int forced = [] {
+        const char* e = getenv("MSSR_GEMM_TILE");
+        return e ? atoi(e) : 0;
+    }();
+    if (forced) return forced;
+    const auto tiles = [&](int bm, int bn) { return ((m + bm - 1) / bm) * ((n + bn - 1) / bn) * batch; };
+    // measured (scratch/gemm_bench.py, bf16 NT): 128x128 wins from ~1000 tiles on (32768 x 512 x 512: 93 vs 105 us),
+    // 64x128 never beat 64x64; 64x64 is best in between
+    if (m >= 128 && n >= 128 && tiles(128, 128) >= 1024) return 128128;
+    return use_tile64(m, n, batch) ? 6464 : 3232;
+}
 
 template <typename TI, typename TO>
 static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
-    if (use_tile64(a.m, a.n, batch)) {
+    const int t = pick_tile(a.m, a.n, batch);
+    if (t == 128128) {
+        dim3 grid((unsigned)((a.n + 127) / 128), (unsigned)((a.m + 127) / 128), (unsigned)batch);
+        klaunch(gemm_kernel<TI, TO, 128, 128>, grid, dim3(GEMM_THREADS), 0, s, a);
+    } else if (t == 64128) {
+        dim3 grid((unsigned)((a.n + 127) / 128), (unsigned)((a.m + 63) / 64), (unsigned)batch);
+        klaunch(gemm_kernel<TI, TO, 64, 128>, grid, dim3(GEMM_THREADS), 0, s, a);
+    } else if (t == 6464) {
         dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 63) / 64), (unsigned)batch);
         klaunch(gemm_kernel<TI, TO, 64, 64>, grid, dim3(GEMM_THREADS), 0, s, a);
     } else {

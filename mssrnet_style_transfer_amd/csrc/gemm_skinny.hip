@@ -262,6 +262,10 @@ bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch) {
     }();
     if (a.m < 1 || a.m > (a.ln_colsum ? (int64_t)SK_MAX_M : max_m) || (a.m + 31) / 32 > 65535 || a.k < 32 || a.k % 32 != 0) return false;
     if (a.a_cs != 1 || a.b_rs != 1) return false;                       // both operands k-contiguous
+    // many rows AND many columns: the LDS-tiled kernel reuses operands, the K-split tiles re-read them through L2
+    // (2560 x 1024 x 512: 22 vs 28 us, 4080 x 1024 x 256: 18 vs 41 us, 1440 x 9606 x 256: 56 vs 127 us); with
+    // n <= 512 the K-split kernel still wins (2560 x 512 x 1024: 23 vs 36 us)
+    if (!a.ln_colsum && a.m > 1024 && a.n >= 1024) return false;
     if (a.a_rs % 8 != 0 || a.b_cs % 8 != 0 || !aligned(a.a, 16) || !aligned(a.b, 16)) return false;
     const int ks = gemm_skinny_ksplit(a.k);
     if (ks > 1 && (!a.partial || a.ln_colsum)) return false;             // no workspace / LN needs whole rows
