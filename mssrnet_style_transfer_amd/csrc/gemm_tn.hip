@@ -9,6 +9,7 @@
 // lane one column of a 4-row block: two of them are one 16x16x32 operand.  No scalar LDS traffic, no
 // transposed copy of the activations in HBM.
 #include "gemm_common.hpp"
+#include <stdlib.h>
 
 namespace mssr {
 
@@ -162,7 +163,18 @@ bool gemm_tn_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, 
     t.b_vec = aligned(g.b, 16) && g.b_rs % 8 == 0 && g.b_bo % 8 == 0 && g.b_bi % 8 == 0;
     const int64_t tiles64 = ((g.m + 63) / 64) * ((g.n + 63) / 64) * batch;
     if ((g.m + 31) / 32 > 65535 || batch > 65535) return false;
-    if (tiles64 >= 128) {
+    // 128x128 tiles (16 MFMAs per wave and LDS barrier instead of 4) once there are >= 1.5 tiles per CU: 12 x 1536 x
+    // 512 x 4480 236 -> 161 us (524 TFLOP/s); with 192-304 tiles the 64x64 tile's finer grain wins (84 vs 113 us)
+    static const int64_t t128_min = [] {
+        const char* e = getenv("MSSR_TN_T128_MIN");
+        return e ? (int64_t)atoll(e) : (int64_t)384;
+    }();
+    const int64_t tiles128 = ((g.m + 127) / 128) * ((g.n + 127) / 128) * batch;
+    if (g.m >= 128 && g.n >= 128 && tiles128 >= t128_min) {
+        const dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)batch);
+        if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 128>, grid, dim3(TN_THREADS), 0, s, t);
+        else klaunch(gemm_tn_kernel<bf16, 128>, grid, dim3(TN_THREADS), 0, s, t);
+    } else if (tiles64 >= 128) {
         const dim3 grid((unsigned)((g.n + 63) / 64), (unsigned)((g.m + 63) / 64), (unsigned)batch);
         if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 64>, grid, dim3(TN_THREADS), 0, s, t);
         else klaunch(gemm_tn_kernel<bf16, 64>, grid, dim3(TN_THREADS), 0, s, t);
