@@ -164,6 +164,9 @@ int mssr_gate_gt0(const void* x, const void* gate, void* y, int64_t n, int dtype
 /* out[n] (+)= sum over rows of x[rows, n] (Linear bias gradient). */
 int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int accumulate,
                 int dtype, void* stream);
+/* The same for `batch` matrices x_bs elements apart (the bias gradients of all layers at once): out [batch, n]. */
+int mssr_colsum_batched(const void* x, float* out, int batch, int64_t x_bs, int64_t rows, int n, int64_t ldx,
+                        int dtype, void* stream);
 /* y = a*x + b*z elementwise (z may be NULL). */
 int mssr_axpby(const void* x, const void* z, void* y, int64_t n, float a, float b, int dtype,
                void* stream);

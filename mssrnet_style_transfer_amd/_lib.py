@@ -106,6 +106,7 @@ SIGNATURES = {
     "mssr_mask_scale": ([_P, _P, _P, _P, _L, _F, _I, _P], c_int),
     "mssr_gate_gt0": ([_P, _P, _P, _L, _I, _P], c_int),
     "mssr_colsum": ([_P, _P, _L, _I, _L, _I, _I, _P], c_int),
+    "mssr_colsum_batched": ([_P, _P, _I, _L, _L, _I, _L, _I, _P], c_int),
     "mssr_axpby": ([_P, _P, _P, _L, _F, _F, _I, _P], c_int),
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),

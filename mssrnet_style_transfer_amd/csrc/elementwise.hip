@@ -106,10 +106,12 @@ __global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(const T* __restrict__ x
 // partial results combined with float atomics (out zeroed by the host call unless accumulate).
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
-                                                     int n, int64_t ldx) {
+                                                     int n, int64_t ldx, int64_t x_bs, int64_t out_bs) {
     __shared__ float sm[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + tx;
+    x += (int64_t)blockIdx.z * x_bs;            // batch of matrices (gridDim.z), one output row each
+    out += (int64_t)blockIdx.z * out_bs;
     float s = 0.f;
     if (c < n) {
         for (int64_t r = (int64_t)blockIdx.y * 4 + ty; r < rows; r += (int64_t)gridDim.y * 4)
@@ -257,10 +259,29 @@ extern "C" int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64
     if (gy > 64) gy = 64;
     const dim3 grid((n + 63) / 64, (unsigned)gy);
     if (dtype == MSSR_F32)
-        colsum_kernel<float><<<grid, dim3(256), 0, s>>>((const float*)x, out, rows, n, ldx);
+        colsum_kernel<float><<<grid, dim3(256), 0, s>>>((const float*)x, out, rows, n, ldx, 0, 0);
     else
-        colsum_kernel<bf16><<<grid, dim3(256), 0, s>>>((const bf16*)x, out, rows, n, ldx);
+        colsum_kernel<bf16><<<grid, dim3(256), 0, s>>>((const bf16*)x, out, rows, n, ldx, 0, 0);
     MSSR_LAUNCH_OK("colsum");
+}
+
+extern "C" int mssr_colsum_batched(const void* x, float* out, int batch, int64_t x_bs, int64_t rows, int n, int64_t ldx,
+                                   int dtype, void* stream) {
+    MSSR_REQUIRE(valid_dtype(dtype), "colsum_batched: bad dtype %d", dtype);
+    MSSR_REQUIRE(batch > 0 && batch <= 65535 && rows >= 0 && n > 0 && ldx >= n && x_bs >= 0,
+                 "colsum_batched: bad shape batch=%d rows=%lld n=%d ldx=%lld", batch, (long long)rows, n, (long long)ldx);
+    MSSR_REQUIRE(out && (x || rows == 0), "colsum_batched: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * batch, s);
+    if (rows == 0) return MSSR_OK;
+    int64_t gy = (rows + 63) / 64;
+    if (gy > 64) gy = 64;
+    const dim3 grid((n + 63) / 64, (unsigned)gy, (unsigned)batch);
+    if (dtype == MSSR_F32)
+        colsum_kernel<float><<<grid, dim3(256), 0, s>>>((const float*)x, out, rows, n, ldx, x_bs, n);
+    else
+        colsum_kernel<bf16><<<grid, dim3(256), 0, s>>>((const bf16*)x, out, rows, n, ldx, x_bs, n);
+    MSSR_LAUNCH_OK("colsum_batched");
 }
 
 extern "C" int mssr_embedding_fwd(const int64_t* ids, const float* weight, const float* pe, void* out, int64_t rows,

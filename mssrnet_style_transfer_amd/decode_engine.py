@@ -158,15 +158,13 @@ def _bgemm_t(dy, x):
 
 
 def _bsum(dy):
-    """column sums of dy [NL, R, n] (bias gradients of all layers) -> float [NL, n]; one mssr_colsum per layer."""
-    lib = L.load()
+    """column sums of dy [NL, R, n] (bias gradients of all layers) -> float [NL, n]; one launch for all layers."""
     NL, R, n = dy.shape
-    if dy.stride(-1) != 1 or dy.stride(-2) != n:
+    if dy.stride(-1) != 1 or dy.stride(-2) < n:
         dy = dy.contiguous()
     out = torch.empty(NL, n, dtype=torch.float32, device=dy.device)
-    code, st = L.dt(dy), L.stream()
-    for l in range(NL):
-        L.check(lib.mssr_colsum(dy[l].data_ptr(), out[l].data_ptr(), R, n, n, 0, code, st), "colsum")
+    L.check(L.load().mssr_colsum_batched(dy.data_ptr(), out.data_ptr(), NL, dy.stride(0) if NL > 1 else 0, R, n,
+                                         dy.stride(-2), L.dt(dy), L.stream()), "colsum_batched")
     return out
 
 
