@@ -23,10 +23,13 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None):
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, always=False):
+        """``always``: issue the collectives even for a single rank (an identity reduction), which lets one GPU
+        exercise the RCCL path end to end -- hooks, side stream, async handles -- as the multi-GPU job will run it."""
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group)
                                                                  if dist.is_initialized() else 1)
+        self.active = self.world > 1 or (always and dist.is_initialized())
         self.bucket_bytes = int(bucket_bytes)
         self._plans = {}        # id(module) -> list of buckets
         self._pending = []      # (bucket, work handle)
@@ -80,7 +83,7 @@ class GradSync:
             torch._foreach_copy_(dst, src)
 
     def _launch(self, b):
-        if self.world <= 1:
+        if not self.active:
             b["launched"] = True
             return
         flat = b["flat"]
@@ -113,7 +116,7 @@ class GradSync:
 
     def arm(self, module):
         """Hook the next backward through ``module``: buckets are reduced as they fill."""
-        if self.world <= 1 or not self._overlap_ok(module):
+        if not self.active or not self._overlap_ok(module):
             return
         plan = self._plan(module)
         for b in plan:
@@ -131,7 +134,7 @@ class GradSync:
         for h in self._hooks:
             h.remove()
         self._hooks = []
-        if self.world <= 1:
+        if not self.active:
             return
         for m in modules:
             for b in self._plan(m):
