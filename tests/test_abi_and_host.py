@@ -111,3 +111,31 @@ def test_phase_log_reads_lazily_and_behaves_like_a_dict():
     assert log["x"] == 3.0 and log["z"] == 2.75
     assert dict(log) == {"x": 3.0, "y": 0.25, "z": 2.75} and len(log) == 3
     assert {**log, "k": 1}["y"] == 0.25
+
+
+def test_modules_deepcopy_pickle_and_state_dict_roundtrip():
+    """The reference checkpoints pickled module objects (trainer_wgan_wh.py:1093-1100), deep-copies models for its
+    shadow copies (:129-131) and moves weights with load_state_dict (:1077-1078): the drop-in modules must hold no
+    unpicklable handles (library pointers, packed-weight caches live outside the modules)."""
+    import copy
+    import io
+    import pickle
+    import torch
+    from mssrnet_style_transfer_amd.config import MSSRConfig
+    from mssrnet_style_transfer_amd.style_generator_builder import build_all
+    cfg = MSSRConfig.small()
+    nets = build_all(cfg, device="cpu", seed=3)
+    for name, m in nets.items():
+        twin = copy.deepcopy(m)
+        blob = pickle.dumps(m)
+        back = pickle.loads(blob)
+        buf = io.BytesIO()
+        torch.save(m.state_dict(), buf)
+        buf.seek(0)
+        sd = torch.load(buf, weights_only=True)
+        for other in (twin, back):
+            assert list(other.state_dict().keys()) == list(m.state_dict().keys()), name
+            missing = other.load_state_dict(sd)
+            assert not missing.missing_keys and not missing.unexpected_keys, name
+            for (k, a), (_, b) in zip(m.state_dict().items(), other.state_dict().items()):
+                assert torch.equal(a, b), (name, k)
