@@ -26,6 +26,7 @@ struct TnArgs {
     int64_t batch_inner, a_bo, a_bi, b_bo, b_bi, c_bo, c_bi;
     float alpha, beta;
     int a_vec, b_vec;
+    int ksplit;         // > 1: blockIdx.z = batch * ksplit + slice, fp32 C pre-set (zero or beta*C), partial sums by atomics
 };
 
 // one [TN_BK][W] tile: every thread owns W*TN_BK/8/256 chunks of 8 elements
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs p) {
     __shared__ __attribute__((aligned(16))) short Bs[TN_BK * LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+    const int64_t zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
+    const int64_t zo = zb / p.batch_inner, zi = zb % p.batch_inner;
     const bf16* A = p.a + zo * p.a_bo + zi * p.a_bi;
     const bf16* B = p.b + zo * p.b_bo + zi * p.b_bi;
     const int64_t m0 = (int64_t)blockIdx.y * BT, n0 = (int64_t)blockIdx.x * BT;
@@ -106,10 +108,12 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs p) {
 #pragma unroll
         for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     TnLoader<BT> la, lb;
-    const int64_t nk = (p.k + TN_BK - 1) / TN_BK;
-    la.fetch(A, p.lda, 0, m0, p.k, p.m, p.a_vec);
-    lb.fetch(B, p.ldb, 0, n0, p.k, p.n, p.b_vec);
-    for (int64_t t = 0; t < nk; ++t) {
+    const int64_t nk_all = (p.k + TN_BK - 1) / TN_BK;
+    const int64_t per = (nk_all + p.ksplit - 1) / p.ksplit;            // k-tiles of this slice
+    const int64_t t_begin = zs * per, nk = t_begin + per < nk_all ? t_begin + per : nk_all;
+    la.fetch(A, p.lda, t_begin * TN_BK, m0, p.k, p.m, p.a_vec);
+    lb.fetch(B, p.ldb, t_begin * TN_BK, n0, p.k, p.n, p.b_vec);
+    for (int64_t t = t_begin; t < nk; ++t) {
         la.commit(As);
         lb.commit(Bs);
         __syncthreads();
@@ -140,6 +144,10 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs p) {
                 const int64_t row = m0 + wm * WT + i * 16 + (lane >> 4) * 4 + r;
                 if (row >= p.m) continue;
                 float v = p.alpha * acc[i][j][r];
+                if (p.ksplit > 1) {
+                    if constexpr (sizeof(TO) == 4) atomicAdd(reinterpret_cast<float*>(C) + row * p.ldc + col, v);
+                    continue;
+                }
                 if (p.beta != 0.f) v += p.beta * to_f(C[row * p.ldc + col]);
                 C[row * p.ldc + col] = from_f<TO>(v);
             }
@@ -163,6 +171,25 @@ bool gemm_tn_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, 
     t.b_vec = aligned(g.b, 16) && g.b_rs % 8 == 0 && g.b_bo % 8 == 0 && g.b_bi % 8 == 0;
     const int64_t tiles64 = ((g.m + 63) / 64) * ((g.n + 63) / 64) * batch;
     if ((g.m + 31) / 32 > 65535 || batch > 65535) return false;
+    // Few output tiles and a long reduction (a critic's 256 x 256 weight over 33 280 rows: 64 blocks, 1 040 k-tiles
+    // each, 900 us): slice K over blockIdx.z and add the partial tiles with fp32 atomics into the pre-set output.
+    t.ksplit = 1;
+    {
+        const int64_t blocks = tiles64 >= 128 ? tiles64 : ((g.m + 31) / 32) * ((g.n + 31) / 32) * batch;
+        const bool plain_c = out_dtype == MSSR_F32 && g.ldc == g.n && (batch == 1 || (g.c_bi == g.m * g.n && g.batch_inner == batch));
+        if (blocks < 256 && g.k >= 4096 && plain_c && (g.beta == 0.f || g.beta == 1.f)) {
+            int64_t ks = (512 + blocks - 1) / blocks;
+            if (ks > g.k / 1024) ks = g.k / 1024;
+            if (ks > 32) ks = 32;
+            if (ks * batch > 65535) ks = 65535 / batch;
+            if (ks > 1) {
+                t.ksplit = (int)ks;
+                if (g.beta == 0.f && hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)(g.m * g.n * batch), s) != hipSuccess)
+                    return false;
+            }
+        }
+    }
+    const unsigned gz = (unsigned)(batch * t.ksplit);
     // 128x128 tiles (16 MFMAs per wave and LDS barrier instead of 4) once there are >= 1.5 tiles per CU: 12 x 1536 x
     // 512 x 4480 236 -> 161 us (524 TFLOP/s); with 192-304 tiles the 64x64 tile's finer grain wins (84 vs 113 us)
     static const int64_t t128_min = [] {
@@ -171,15 +198,15 @@ bool gemm_tn_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, 
     }();
     const int64_t tiles128 = ((g.m + 127) / 128) * ((g.n + 127) / 128) * batch;
     if (g.m >= 128 && g.n >= 128 && tiles128 >= t128_min) {
-        const dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), (unsigned)batch);
+        const dim3 grid((unsigned)((g.n + 127) / 128), (unsigned)((g.m + 127) / 128), gz);
         if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 128>, grid, dim3(TN_THREADS), 0, s, t);
         else klaunch(gemm_tn_kernel<bf16, 128>, grid, dim3(TN_THREADS), 0, s, t);
     } else if (tiles64 >= 128) {
-        const dim3 grid((unsigned)((g.n + 63) / 64), (unsigned)((g.m + 63) / 64), (unsigned)batch);
+        const dim3 grid((unsigned)((g.n + 63) / 64), (unsigned)((g.m + 63) / 64), gz);
         if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 64>, grid, dim3(TN_THREADS), 0, s, t);
         else klaunch(gemm_tn_kernel<bf16, 64>, grid, dim3(TN_THREADS), 0, s, t);
     } else {
-        const dim3 grid((unsigned)((g.n + 31) / 32), (unsigned)((g.m + 31) / 32), (unsigned)batch);
+        const dim3 grid((unsigned)((g.n + 31) / 32), (unsigned)((g.m + 31) / 32), gz);
         if (out_dtype == MSSR_F32) klaunch(gemm_tn_kernel<float, 32>, grid, dim3(TN_THREADS), 0, s, t);
         else klaunch(gemm_tn_kernel<bf16, 32>, grid, dim3(TN_THREADS), 0, s, t);
     }

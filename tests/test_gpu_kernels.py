@@ -577,7 +577,9 @@ def test_gemm_skinny_layernorm_prologue(ops, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(512, 512, 1280, 1), (1536, 512, 2240, 3), (130, 70, 100, 1), (9606, 256, 512, 1),
-                                         (64, 64, 64, 2), (48, 1024, 333, 1)])
+                                         (64, 64, 64, 2), (48, 1024, 333, 1),
+                                         # few output tiles, long reduction: K sliced over blockIdx.z, fp32 atomics
+                                         (256, 256, 33280, 1), (130, 70, 9000, 1), (64, 192, 8192, 3)])
 def test_gemm_tn_weight_gradient_kernel(ops, M, N, K, batch):
     """dW = dY^T X with both operands k-major (gemm_tn.hip: LDS tiles read back through
     ds_read_b64_tr_b16) against fp64, fp32 and bf16 outputs, beta accumulation, batched over layers,
@@ -598,6 +600,10 @@ def test_gemm_tn_weight_gradient_kernel(ops, M, N, K, batch):
     want = acc.double() * 0.5 + 2.0 * ref
     ops.gemm(dy.transpose(1, 2), x, False, torch.float32, out=acc, alpha=2.0, beta=0.5)
     assert_close(acc, want, 3e-5 * math.sqrt(K), "tn alpha/beta")
+    acc1 = torch.randn(batch, M, N, device="cuda")
+    want1 = acc1.double() + ref
+    ops.gemm(dy.transpose(1, 2), x, False, torch.float32, out=acc1, beta=1.0)
+    assert_close(acc1, want1, 3e-5 * math.sqrt(K), "tn accumulate (beta = 1)")
     if batch == 1:          # column slices: leading dimensions that are not multiples of 8, unaligned bases
         dys, xs = dy[0][:, 3:M - 2], x[0][:, 1:N - 4]
         o = ops.gemm(dys.t(), xs, False, torch.float32)
