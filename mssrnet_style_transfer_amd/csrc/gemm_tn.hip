@@ -177,8 +177,8 @@ bool gemm_tn_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, 
     {
         const int64_t blocks = tiles64 >= 128 ? tiles64 : ((g.m + 31) / 32) * ((g.n + 31) / 32) * batch;
         const bool plain_c = out_dtype == MSSR_F32 && g.ldc == g.n && (batch == 1 || (g.c_bi == g.m * g.n && g.batch_inner == batch));
-        if (blocks < 256 && g.k >= 4096 && plain_c && (g.beta == 0.f || g.beta == 1.f)) {
-            int64_t ks = (512 + blocks - 1) / blocks;
+        if (blocks < 512 && g.k >= 4096 && plain_c && (g.beta == 0.f || g.beta == 1.f)) {
+            int64_t ks = (1024 + blocks - 1) / blocks;
             if (ks > g.k / 1024) ks = g.k / 1024;
             if (ks > 32) ks = 32;
             if (ks * batch > 65535) ks = 65535 / batch;
