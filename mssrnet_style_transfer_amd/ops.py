@@ -158,7 +158,7 @@ def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, a
     d.alpha, d.beta, d.relu = alpha, beta, int(relu)
     d.in_dtype, d.out_dtype = L.dt(a), L.dt(out)
     d.drop_p, d.drop_seed, d.no_skinny = drop_p, drop_seed, int(no_skinny)
-    if k > 2048 and (m <= 128 or m * n * ((k + 2047) // 2048) <= (8 << 20)):
+    if k > 2048 and (m <= 128 or m * n * ((k + 1023) // 1024) <= (8 << 20)):
         ws = _workspace(a.device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if ln is not None:
