@@ -262,3 +262,33 @@ def test_two_consecutive_steps_follow_the_oracle(ops):
     shadows, packed engine weights) must follow the fused-Adam updates, which do not bump Parameter._version."""
     import __graft_entry__ as g
     g.smoke()
+
+
+def test_training_loop_learns_and_keeps_memory_flat(ops):
+    """Forty optimizer steps of the reconstruct / discriminator / generator schedule in bf16 on two alternating
+    batches of different shape: the reconstruction loss must fall (weights, packed-weight caches and optimizer state
+    stay coherent across steps and shapes) and device memory must not grow."""
+    from mssrnet_style_transfer_amd.style_generator_builder import build_all
+    from mssrnet_style_transfer_amd.synth import make_batch
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    ops.set_compute_dtype(torch.bfloat16)
+    cfg = MSSRConfig.small(learning_rate=1e-3)
+    nets = build_all(cfg, device="cuda", seed=5)
+    tr = Trainer(nets, cfg)
+    batches = [make_batch(12, 9, cfg.vocab_size, seed=1, device="cuda"), make_batch(8, 6, cfg.vocab_size, seed=2, device="cuda")]
+    first, last, mem = {}, {}, []
+    for i in range(40):
+        b = batches[i % 2]
+        r = tr.train_reconstruct(b)
+        if i % 4 == 3:
+            tr.train_discriminator(b)
+            g = tr.train_generator(b)
+            assert all(v == v for v in g.values())
+        first.setdefault(i % 2, r["T_CONSTRUCT_R_VL"])
+        last[i % 2] = r["T_CONSTRUCT_R_VL"]
+        if i in (9, 39):
+            torch.cuda.synchronize()
+            mem.append(torch.cuda.memory_allocated())
+    for k in (0, 1):
+        assert last[k] < 0.8 * first[k], (k, first[k], last[k])
+    assert mem[1] <= mem[0] * 1.05 + (1 << 20), mem
