@@ -117,7 +117,8 @@ int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
  * event pair handed to hipExtLaunchKernelGGL on the stream it is enqueued on (begin / end of the dispatch
  * itself, the interval rocprofv3's kernel trace reports; ms < 0: nothing was launched).  kernel: 0 = gemm_kernel (tile = 32/64),
  * 1 = gemm_skinny_kernel (tile = 16/32 output tile edge, ksplit = split-K slabs, ln = LayerNorm prologue),
- * 2 = gemm_tn_kernel (both operands k-major: weight gradients).
+ * 2 = gemm_tn_kernel (both operands k-major: weight gradients), 3 = gemm_lnb_kernel (LayerNorm backward fused with the
+ * product behind it: decode engine only).
  * Host-side only. */
 typedef struct {
     int kernel, in_dtype, out_dtype, tile, ksplit, ln;
@@ -340,7 +341,7 @@ typedef struct {
     /* backward only (NULL for forward-only plans) */
     float* dprobs;                /* [T][B, V] in: dL/dprobs; the feedback path accumulates into it */
     void* dlogits;                /* [T][B, Vp], padded columns zero */
-    void* dX;                     /* [B, d] */
+    void* dX;                     /* [2][B, d]: running residual-stream gradient, two buffers used in turn */
     void* dqkv;                   /* [n_layers][T][B, 3d] */
     void* dactD;                  /* [n_layers][7][T][B, d]  dn1|d_so|dn2|d_cq|d_co|dn3|d_f2 */
     void* dactF;                  /* [n_layers][T][B, ff]    d_f1 */

@@ -12,6 +12,7 @@
 // gradient of every GEMM output in a slab and the caller contracts each slab once at the end
 // (dW = dY_all^T X_all with a long reduction dimension instead of 28 products of depth 80).
 #include "engine_common.hpp"
+#include "gemm_common.hpp"
 #include <stdlib.h>
 #include <thread>
 #include <initializer_list>
@@ -871,7 +872,7 @@ struct Geo {
     const uint8_t* src_mask() const { return p->src_mask + (int64_t)r0 * Ls; }
     char* tmp() const { return at(p->tmp, (int64_t)r0 * d, es); }
     char* logits() const { return at(p->logits, (int64_t)r0 * Vp, es); }
-    char* dX() const { return at(p->dX, (int64_t)r0 * d, es); }
+    char* dX(int which) const { return at(p->dX, ((int64_t)which * B + r0) * d, es); }     // two buffers, used in turn
 };
 
 static int step_fwd(const Ctx& c, int step) {
@@ -1025,33 +1026,71 @@ static int step_bwd(const Ctx& c, int step) {
     if ((rc = gemm_nt(c, dlg, p->Vp, p->wt_gen, p->Vp, dnf, d, R, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                       0.f, c.dt, 0.f, 0)))
         return rc;
-    char* dx = G.dX();                         // running gradient of the residual stream [R,d]
-    ln_bwd(dnf, G.X(NL), p->lnF_g, NL * 3, nullptr, dx, G.dact(NL - 1, G_DF2, step), site_seed(c, step, NL - 1, 6), 1.f);
+    // running gradient of the residual stream [R,d]: two buffers, every LayerNorm backward reads one and writes the
+    // other (in the fused form other thread blocks still read the old one while the new one is written)
+    char* dxb[2] = {G.dX(0), G.dX(1)};
+    int cur = 0;                               // dxb[cur] holds the current gradient (after the first ln step)
+    // LayerNorm backward + the Linear backward behind it.  Fused (bf16, d <= 512): ONE launch, the product's A
+    // operand dx2 is formed in its prologue (gemm_lnb.hip); otherwise two launches.
+    static const bool fuse_env = [] {
+        const char* e = getenv("MSSR_DECODE_FUSE_LNB");
+        return !(e && e[0] == '0');
+    }();
+    const bool fuse_lnb = fuse_env && c.dt == MSSR_BF16;
+    auto ln_gemm = [&](const void* dy, const void* x, const float* g, int idx, bool first, void* dx2, uint64_t seed,
+                       const void* w, int64_t ldw, void* out, int64_t n, const void* gate, int64_t ldg,
+                       float alpha) -> int {
+        const void* dres = first ? nullptr : dxb[cur];
+        void* dxo = first ? dxb[cur] : dxb[cur ^ 1];
+        if (!first) cur ^= 1;
+        if (fuse_lnb) {
+            mssr_gemm_desc ds;
+            ds.a = dy; ds.b = w; ds.c = out; ds.bias = nullptr; ds.residual = nullptr; ds.gate = gate;
+            ds.m = R; ds.n = n; ds.k = d;
+            ds.a_rs = d; ds.a_cs = 1; ds.b_rs = 1; ds.b_cs = ldw;
+            ds.ldc = n; ds.ldr = 0; ds.ldg = ldg;
+            ds.batch_outer = ds.batch_inner = 1;
+            ds.a_bo = ds.a_bi = ds.b_bo = ds.b_bi = ds.c_bo = ds.c_bi = 0;
+            ds.alpha = alpha; ds.beta = 0.f; ds.relu = 0;
+            ds.in_dtype = c.dt; ds.out_dtype = c.dt;
+            ds.drop_p = 0.f; ds.drop_seed = 0;
+            ds.workspace = nullptr; ds.workspace_bytes = 0; ds.no_skinny = 0;
+            ds.ln_colsum = nullptr; ds.ln_mean = nullptr; ds.ln_rstd = nullptr; ds.ln_eps = 0.f;
+            GemmArgs a;
+            gemm_fill_args(&ds, a);
+            a.lnb_x = x; a.lnb_gamma = g; a.lnb_mean = G.stat(idx, 0); a.lnb_rstd = G.stat(idx, 1);
+            a.lnb_dres = dres; a.lnb_dx = dxo; a.lnb_dx2 = dx2;
+            a.lnb_p = pd; a.lnb_extra = 1.f; a.lnb_seed = seed;
+            const int pi = prof_begin(c.s);
+            const bool done = gemm_lnb_try(a, c.dt, c.s);
+            prof_end(pi, c.s, 3, c.dt, c.dt, 32, 1, R, n, d, 1, 2);        // nothing launched: the record keeps ms = -1
+            if (done) return MSSR_OK;
+        }
+        ln_bwd(dy, x, g, idx, dres, dxo, dx2, seed, 1.f);
+        return gemm_nt(c, dx2, d, w, ldw, out, n, R, n, d, nullptr, 0, nullptr, 0, gate, ldg, alpha, 0.f, c.dt, 0.f, 0);
+    };
+    // final LayerNorm -> d_f2 of the last layer -> d_f1 = (d_f2 . W2) * (inter > 0) / (1-p)   [W as [N=ff, K=d] = wt_2]
+    if ((rc = ln_gemm(dnf, G.X(NL), p->lnF_g, NL * 3, true, G.dact(NL - 1, G_DF2, step), site_seed(c, step, NL - 1, 6),
+                      p->layers[NL - 1].wt_2, d, G.dinter(NL - 1, step), ff, G.inter(NL - 1), ff, keep)))
+        return rc;
     for (int l = NL - 1; l >= 0; --l) {
         const mssr_dec_layer& L = p->layers[l];
         char *h1 = G.act(l, K_H1), *qc = G.act(l, K_QC), *h2 = G.act(l, K_H2);
-        char* inter = G.inter(l);
         char *dn1 = G.dact(l, G_DN1, step), *d_so = G.dact(l, G_DSO, step), *dn2 = G.dact(l, G_DN2, step),
-             *d_cq = G.dact(l, G_DCQ, step), *d_co = G.dact(l, G_DCO, step), *dn3 = G.dact(l, G_DN3, step),
-             *d_f2 = G.dact(l, G_DF2, step);
+             *d_cq = G.dact(l, G_DCQ, step), *d_co = G.dact(l, G_DCO, step), *dn3 = G.dact(l, G_DN3, step);
         char* d_f1 = G.dinter(l, step);
         char* qkv_0 = G.qkv(l, 0);
         char* qkv_s = G.qkv(l, step);
         char* dqkv_s = G.dqkv(l, step);
-        // --- feed forward block: y = h2 + drop(W2 inter + b2), inter = drop(relu(W1 n3 + b1));
-        //     d_f2 (gradient of the W2 output) was written by the LayerNorm backward above this layer
-        // d_f1 = (d_f2 . W2) * (inter > 0) / (1-p)      [W as [N=ff, K=d] = wt_2]
-        if ((rc = gemm_nt(c, d_f2, d, L.wt_2, d, d_f1, ff, R, ff, d, nullptr, 0, nullptr, 0, inter, ff, keep, 0.f, c.dt,
-                          0.f, 0)))
-            return rc;
+        // --- feed forward block: y = h2 + drop(W2 inter + b2), inter = drop(relu(W1 n3 + b1)); d_f1 (gradient of
+        //     inter) was formed together with the LayerNorm backward above this layer
         if ((rc = gemm_nt(c, d_f1, ff, L.wt_1, ff, dn3, d, R, d, ff, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;
-        ln_bwd(dn3, h2, L.lnf_g, l * 3 + 2, dx, dx, d_co, site_seed(c, step, l, 4), 1.f);   // dx <- grad wrt h2
-        // --- context attention block: h2 = h1 + drop(Wco ctx2 + bco)
+        // --- context attention block: h2 = h1 + drop(Wco ctx2 + bco); LN3 backward (dx <- grad wrt h2) + out-proj
         char* dctx2 = G.dctx(l, 1, step);
-        if ((rc = gemm_nt(c, d_co, d, L.wt_co, d, dctx2, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
-                          0.f, 0)))
+        if ((rc = ln_gemm(dn3, h2, L.lnf_g, l * 3 + 2, false, d_co, site_seed(c, step, l, 4), L.wt_co, d, dctx2, d, nullptr,
+                          0, 1.f)))
             return rc;
         {
             const char* mkv = G.mem_kv(l);
@@ -1063,11 +1102,10 @@ static int step_bwd(const Ctx& c, int step) {
         if ((rc = gemm_nt(c, d_cq, d, L.wt_cq, d, dn2, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
                           0.f, 0)))
             return rc;
-        ln_bwd(dn2, h1, L.ln2_g, l * 3 + 1, dx, dx, d_so, site_seed(c, step, l, 2), 1.f);   // dx <- grad wrt h1
-        // --- self attention block: h1 = x + drop(Wso ctx1 + bso)
+        // --- self attention block: h1 = x + drop(Wso ctx1 + bso); LN2 backward (dx <- grad wrt h1) + out-proj
         char* dctx1 = G.dctx(l, 0, step);
-        if ((rc = gemm_nt(c, d_so, d, L.wt_so, d, dctx1, d, R, d, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
-                          0.f, 0)))
+        if ((rc = ln_gemm(dn2, h1, L.ln2_g, l * 3 + 1, false, d_so, site_seed(c, step, l, 2), L.wt_so, d, dctx1, d, nullptr,
+                          0, 1.f)))
             return rc;
         DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
                 (int64_t)B * 3 * d, nullptr, 0, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
@@ -1076,14 +1114,19 @@ static int step_bwd(const Ctx& c, int step) {
         if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))
             return rc;
-        // dx <- grad wrt the layer input; below it sits layer l-1's W2 output, or (l = 0) the embedding
-        // x0 = drop(e*sqrt(d) + pe), whose gradient d_e also takes the sqrt(d)
-        if (l > 0)
-            ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dx, dx, G.dact(l - 1, G_DF2, step), site_seed(c, step, l - 1, 6),
-                   1.f);
-        else
-            ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dx, dx, G.rows(p->d_e, step, d), site_seed(c, step, -1, 0),
-                   sqrtf((float)d));
+        // LN1 backward: dx <- grad wrt the layer input; below it sits layer l-1's W2 output (its gradient d_f2 and the
+        // product d_f1 = (d_f2 . W2) * gate in the same launch), or (l = 0) the embedding x0 = drop(e*sqrt(d) + pe),
+        // whose gradient d_e also takes the sqrt(d)
+        if (l > 0) {
+            if ((rc = ln_gemm(dn1, G.X(l), L.ln1_g, l * 3 + 0, false, G.dact(l - 1, G_DF2, step),
+                              site_seed(c, step, l - 1, 6), p->layers[l - 1].wt_2, d, G.dinter(l - 1, step), ff,
+                              G.inter(l - 1), ff, keep)))
+                return rc;
+        } else {
+            ln_bwd(dn1, G.X(l), L.ln1_g, l * 3 + 0, dxb[cur], dxb[cur ^ 1], G.rows(p->d_e, step, d),
+                   site_seed(c, step, -1, 0), sqrtf((float)d));
+            cur ^= 1;
+        }
     }
     char* de = G.rows(p->d_e, step, d);
     if (step > 0) {

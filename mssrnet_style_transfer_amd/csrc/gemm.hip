@@ -209,7 +209,9 @@ using namespace mssr;
 
 extern "C" int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch) { return use_tile64(m, n, batch) ? 64 : 32; }
 
-static void fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
+void mssr::gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
+    a.lnb_x = nullptr; a.lnb_gamma = a.lnb_mean = a.lnb_rstd = nullptr; a.lnb_dres = nullptr; a.lnb_dx = a.lnb_dx2 = nullptr;
+    a.lnb_p = 0.f; a.lnb_extra = 1.f; a.lnb_seed = 0;
     a.a = d->a; a.b = d->b; a.c = d->c; a.bias = d->bias; a.residual = d->residual; a.gate = d->gate;
     a.m = d->m; a.n = d->n; a.k = d->k;
     a.a_rs = d->a_rs; a.a_cs = d->a_cs; a.b_rs = d->b_rs; a.b_cs = d->b_cs;
@@ -237,7 +239,7 @@ static void fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
 extern "C" int mssr_gemm_is_skinny(const mssr_gemm_desc* d) {
     if (!d || d->no_skinny || !valid_dtype(d->in_dtype)) return 0;
     GemmArgs a;
-    fill_args(d, a);
+    gemm_fill_args(d, a);
     return gemm_skinny_eligible(a, d->in_dtype, d->batch_outer * d->batch_inner) ? 1 : 0;
 }
 
@@ -262,7 +264,7 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
 
     MSSR_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of [0,1)", d->drop_p);
     GemmArgs a;
-    fill_args(d, a);
+    gemm_fill_args(d, a);
     hipStream_t s = (hipStream_t)stream;
     const int pi = prof_begin(s);
     if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {

@@ -27,6 +27,19 @@ struct GemmArgs {
     float* ln_mean;
     float* ln_rstd;
     float ln_eps;
+    // LayerNorm-BACKWARD prologue (gemm_lnb.hip): `a` holds dy, the gradient of a LayerNorm output, and the A operand
+    // of the product is  dx2 = dropout_replay(dx),  dx = dres + rstd (g - mean(g) - xhat mean(g xhat)),  g = gamma * dy
+    // (ln_bwd_dx_kernel's math, engine_common.hpp); the blocks of tile column 0 also store dx and dx2.  Every row
+    // operand has the row stride a_rs.  dres must not alias dx (other blocks still read it).
+    const void* lnb_x;
+    const float* lnb_gamma;
+    const float* lnb_mean;
+    const float* lnb_rstd;
+    const void* lnb_dres;
+    void* lnb_dx;
+    void* lnb_dx2;
+    float lnb_p, lnb_extra;
+    uint64_t lnb_seed;
 };
 
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
@@ -52,6 +65,10 @@ bool gemm_skinny_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t bat
 bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch);
 // returns true when the k-major ("TN", weight-gradient) kernel took the problem (gemm_tn.hip)
 bool gemm_tn_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
+// LayerNorm backward fused with the product behind it (a.lnb_* set): false when the shape is outside its reach
+bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s);
+// mssr_gemm_desc -> GemmArgs (gemm.hip); the lnb_* fields are cleared
+void gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a);
 int gemm_skinny_ksplit(int64_t k);
 int gemm_skinny_tile(int64_t m, int64_t n, int64_t k);     // 16 or 32: output tile edge the K-split kernel uses
 

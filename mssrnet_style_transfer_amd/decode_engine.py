@@ -245,7 +245,7 @@ class _SoftDecode(Function):
         z = lambda *shape, dtype=cd: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
         g = dict(dprobs=dprobs.to(torch.float32).clone(memory_format=torch.contiguous_format),
-                 dlogits=z(R, Vp), dX=e(B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
+                 dlogits=z(R, Vp), dX=e(2, B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
                  dctx=e(NL, 2, R, d), ds_self=e(NL, 2, T, B * H, T, dtype=torch.float32),
                  ds_ctx=e(NL, 2, T, B * H, Ls, dtype=torch.float32),
                  d_e=e(R, d), dnf=e(R, d))

@@ -186,3 +186,58 @@ def test_engine_smallest_shapes_fp32(ops, B, Ls, steps):
     assert_close(ge_mem, gm_mem, 2e-4, "d memory_bank", floor=1e-9)
     dec_keys = [k for k in gm if k.startswith("decoder.") or k.startswith("generator.")]
     assert_grads({k: ge[k] for k in dec_keys}, {k: gm[k] for k in dec_keys}, 2e-4, "decoder")
+
+
+def test_engine_fused_ln_backward_matches_separate_kernels(ops):
+    """bf16, README widths, dropout ON: the decode backward with LayerNorm-backward folded into the prologue of
+    the Linear backward behind it (gemm_lnb.hip; default) against the same sweep with the two launches kept apart
+    (MSSR_DECODE_FUSE_LNB=0 is read once per process, so each variant runs in a child process).  Both round dx and
+    dx2 to bf16 at the same points and replay the same dropout masks: gradients agree to rounding of the row sums."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+from mssrnet_style_transfer_amd import ops
+from mssrnet_style_transfer_amd.config import MSSRConfig
+from mssrnet_style_transfer_amd import train_and_translate as TT
+from test_gpu_decode_engine import setup
+ops.set_compute_dtype(torch.bfloat16)
+cfg = MSSRConfig(layers=3, dropout=0.2, attention_dropout=0.1)
+B, Ls, steps = 24, 9, 7
+model, src, lens, mem = setup(cfg, B, Ls, seed=11)
+model.train()
+torch.manual_seed(3)
+w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
+ops._state["seed_counter"] = 77
+m = mem.to(torch.bfloat16).clone().requires_grad_(True)
+probs, _, _ = TT.decode_batch_ori(model, cfg, src, None, m, lens, steps)
+(probs * w).sum().backward()
+out = {"probs": probs.detach().float().cpu(), "dmem": m.grad.float().cpu()}
+for k, p in model.named_parameters():
+    if p.grad is not None and (k.startswith("decoder.") or k.startswith("generator.")):
+        out[k] = p.grad.float().cpu()
+torch.save(out, sys.argv[1])
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, env in (("fused", "1"), ("split", "0")):
+            path = os.path.join(tmp, tag + ".pt")
+            e = dict(os.environ, MSSR_DECODE_FUSE_LNB=env)
+            r = subprocess.run([sys.executable, "-c", code, path], env=e, capture_output=True, text=True, timeout=170)
+            assert r.returncode == 0, r.stderr[-2000:]
+            res[tag] = torch.load(path, weights_only=True)
+    assert set(res["fused"]) == set(res["split"]) and len(res["fused"]) > 50
+    assert torch.equal(res["fused"]["probs"], res["split"]["probs"])            # same forward
+    floor = 1e-4 * max(float(v.abs().max()) for k, v in res["split"].items() if k != "probs")
+    worst = 0.0
+    for k in res["fused"]:
+        a, b = res["fused"][k], res["split"][k]
+        scale = float(b.abs().max())
+        err = float((a - b).abs().max())
+        worst = max(worst, err / max(scale, 1e-12))
+        assert err <= 1e-2 * scale + floor, (k, err, scale)
+    print("fused vs split LN backward: worst relative-to-scale error %.2e" % worst)
