@@ -139,3 +139,22 @@ def test_modules_deepcopy_pickle_and_state_dict_roundtrip():
             assert not missing.missing_keys and not missing.unexpected_keys, name
             for (k, a), (_, b) in zip(m.state_dict().items(), other.state_dict().items()):
                 assert torch.equal(a, b), (name, k)
+
+
+def test_update_dropout_reaches_every_site():
+    """update_dropout(dropout, attention_dropout) of the encoder / decoder (onmt/encoders/transformer.py:138-141,
+    onmt/decoders/transformer.py:354-357) must rewrite the rate at every dropout site of every layer."""
+    from mssrnet_style_transfer_amd.config import MSSRConfig
+    from mssrnet_style_transfer_amd.style_generator_builder import build_main_model
+    cfg = MSSRConfig.small(dropout=0.1, attention_dropout=0.1)
+    model = build_main_model(cfg)
+    model.encoder.update_dropout(0.25, 0.35)
+    model.decoder.update_dropout(0.45, 0.55)
+    for layer in model.encoder.transformer:
+        assert layer.dropout.p == 0.25 and layer.self_attn.dropout.p == 0.35
+        assert layer.feed_forward.dropout_1.p == 0.25 and layer.feed_forward.dropout_2.p == 0.25
+    assert model.encoder.embeddings.make_embedding.pe.dropout.p == 0.25
+    for layer in model.decoder.transformer_layers:
+        assert layer.drop.p == 0.45 and layer.self_attn.dropout.p == 0.55 and layer.context_attn.dropout.p == 0.55
+        assert layer.feed_forward.dropout_1.p == 0.45 and layer.feed_forward.dropout_2.p == 0.45
+    assert model.decoder.embeddings.make_embedding.pe.dropout.p == 0.45

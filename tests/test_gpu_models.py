@@ -292,3 +292,45 @@ def test_training_loop_learns_and_keeps_memory_flat(ops):
     for k in (0, 1):
         assert last[k] < 0.8 * first[k], (k, first[k], last[k])
     assert mem[1] <= mem[0] * 1.05 + (1 << 20), mem
+
+
+def test_decoder_map_state_compacts_the_cache(ops):
+    """The reference's greedy loop drops finished sentences with decoder.map_state(index_select)
+    (translator_wh.py:744-746, decoders/transformer.py:274-287): after two cached steps on five sentences the state is
+    cut down to three of them and decoding continues; the result must equal decoding those three from the start."""
+    from mssrnet_style_transfer_amd import style_generator_builder as SB
+    from mssrnet_style_transfer_amd.train_and_translate import convert_to_onehot, generator_probs
+    cfg = MSSRConfig.small()
+    torch.manual_seed(9)
+    model = SB.build_main_model(cfg).cuda().eval()
+    B, Ls = 5, 6
+    lens = torch.tensor([6, 6, 5, 4, 3], device="cuda")
+    src = torch.randint(9, cfg.vocab_size, (Ls, B, 1), device="cuda")
+    mem = torch.randn(Ls, B, cfg.d_model, device="cuda")
+    keep = torch.tensor([0, 2, 3], device="cuda")
+
+    def steps(src_, mem_, lens_, n, select_after=None):
+        model.decoder.init_state(src_, mem_, None)
+        bos = torch.full((lens_.numel(),), cfg.bos_idx, dtype=torch.long, device="cuda")
+        inp = convert_to_onehot(bos, cfg.vocab_size, "cuda").unsqueeze(0)
+        outs = []
+        for s in range(n):
+            dec_out, _ = model.decoder(inp, mem_, memory_lengths=lens_, step=s)
+            probs = generator_probs(model, dec_out, cfg.dec_temperature)
+            outs.append(probs[-1])
+            inp = probs[-1:]
+            if select_after is not None and s == select_after:
+                model.decoder.map_state(lambda t, dim: t.index_select(dim, keep))
+                mem_, lens_, inp = mem_.index_select(1, keep), lens_.index_select(0, keep), inp.index_select(1, keep)
+                assert model.decoder.state["src"].size(1) == keep.numel()
+                for layer_cache in model.decoder.state["cache"].values():
+                    for k, v in layer_cache.items():
+                        assert v is None or v.size(0) == keep.numel(), k
+        return outs
+
+    with torch.no_grad():
+        cut = steps(src, mem, lens, 5, select_after=1)
+        ref = steps(src.index_select(1, keep), mem.index_select(1, keep), lens.index_select(0, keep), 5)
+    for s in range(5):
+        a = cut[s] if s > 1 else cut[s].index_select(0, keep)
+        assert_close(a, ref[s], 1e-4, "step %d" % s)
