@@ -158,3 +158,55 @@ def test_update_dropout_reaches_every_site():
         assert layer.drop.p == 0.45 and layer.self_attn.dropout.p == 0.55 and layer.context_attn.dropout.p == 0.55
         assert layer.feed_forward.dropout_1.p == 0.45 and layer.feed_forward.dropout_2.p == 0.45
     assert model.decoder.embeddings.make_embedding.pe.dropout.p == 0.45
+
+
+def test_module_surface_matches_the_reference_contract():
+    """Attribute and method names the reference's callers reach for: checkpoint keys, the
+    isinstance checks of decoders/transformer.py:153,346, StyleGenerator2 reaching into the encoder
+    (style_generator.py:22,35-46), update_dropout mutating `.dropout.p`."""
+    import torch
+    from torch import nn
+    from mssrnet_style_transfer_amd.config import MSSRConfig
+    from mssrnet_style_transfer_amd.decoders.transformer import TransformerDecoder, TransformerDecoderLayer
+    from mssrnet_style_transfer_amd.encoders.transformer import TransformerEncoder, TransformerEncoderLayer
+    from mssrnet_style_transfer_amd.modules.embeddings import Embeddings, PositionalEncoding
+    from mssrnet_style_transfer_amd.modules.multi_headed_attn import MultiHeadedAttention
+    from mssrnet_style_transfer_amd.modules.position_ffn import PositionwiseFeedForward
+    from mssrnet_style_transfer_amd.style_generator_builder import build_all
+    cfg = MSSRConfig.small()
+    nets = build_all(cfg, device="cpu", seed=1)
+    enc, dec = nets["model"].encoder, nets["model"].decoder
+    assert isinstance(enc, TransformerEncoder) and isinstance(dec, TransformerDecoder)
+    assert isinstance(nets["style_generator"].encoder, TransformerEncoder)
+    mha = enc.transformer[0].self_attn
+    assert isinstance(mha, MultiHeadedAttention) and isinstance(enc.transformer[0], TransformerEncoderLayer)
+    for name in ("linear_keys", "linear_values", "linear_query", "final_linear"):
+        assert isinstance(getattr(mha, name), nn.Linear) and getattr(mha, name).bias is not None
+    for name in ("softmax", "dropout", "dim_per_head", "model_dim", "head_count", "max_relative_positions"):
+        assert hasattr(mha, name), name
+    ffn = enc.transformer[0].feed_forward
+    assert isinstance(ffn, PositionwiseFeedForward)
+    for name in ("w_1", "w_2", "layer_norm", "dropout_1", "relu", "dropout_2"):
+        assert hasattr(ffn, name), name
+    assert ffn.layer_norm.eps == 1e-6 and enc.layer_norm.eps == 1e-6 and dec.layer_norm.eps == 1e-6
+    for name in ("embeddings", "transformer", "layer_norm", "forward", "update_dropout", "from_opt", "_check_args"):
+        assert hasattr(enc, name), name
+    layer = dec.transformer_layers[0]
+    assert isinstance(layer, TransformerDecoderLayer) and isinstance(layer.self_attn, MultiHeadedAttention)
+    for name in ("self_attn", "context_attn", "feed_forward", "layer_norm_1", "layer_norm_2", "drop",
+                 "full_context_alignment", "alignment_heads"):
+        assert hasattr(layer, name), name
+    for name in ("embeddings", "state", "transformer_layers", "_copy", "layer_norm", "alignment_layer", "from_opt",
+                 "init_state", "map_state", "detach_state", "_init_cache", "update_dropout"):
+        assert hasattr(dec, name), name
+    emb = enc.embeddings
+    assert isinstance(emb, Embeddings) and isinstance(emb.make_embedding.pe, PositionalEncoding)
+    assert isinstance(emb.word_lut, nn.Embedding) and emb.emb_luts[0] is emb.word_lut
+    for name in ("word_padding_idx", "word_vec_size", "embedding_size", "load_pretrained_vectors", "update_dropout"):
+        assert hasattr(emb, name), name
+    keys = set(enc.state_dict().keys())
+    assert "embeddings.make_embedding.emb_luts.0.weight" in keys and "embeddings.make_embedding.pe.pe" in keys
+    assert "transformer.0.self_attn.linear_keys.weight" in keys and "transformer.0.feed_forward.layer_norm.bias" in keys
+    dkeys = set(dec.state_dict().keys())
+    assert "transformer_layers.0.context_attn.final_linear.bias" in dkeys and "transformer_layers.0.layer_norm_2.weight" in dkeys
+    assert tuple(enc.state_dict()["embeddings.make_embedding.pe.pe"].shape) == (5000, 1, cfg.d_model)
