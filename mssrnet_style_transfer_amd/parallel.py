@@ -61,8 +61,20 @@ class GradSync:
             for p in ps:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-            plan.append(dict(params=ps, flat=flat, views=views, ready=0, launched=False))
+            plan.append(dict(params=ps, flat=flat, views=views, ready=0, launched=False, armed=False))
         self._plans[id(module)] = plan
+        # gradient hooks are registered ONCE (registering and removing ~400 of them per phase cost ~2 ms of host
+        # time per step); they only count while their bucket is armed
+        for b in plan:
+            for p in b["params"]:
+                def hook(param, b=b):
+                    if not b["armed"]:
+                        return
+                    b["ready"] += 1
+                    if b["ready"] == len(b["params"]) and not b["launched"]:
+                        self._fill(b)
+                        self._launch(b)
+                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
         return plan
 
     def _side_stream(self, device):
@@ -118,24 +130,16 @@ class GradSync:
         """Hook the next backward through ``module``: buckets are reduced as they fill."""
         if not self.active or not self._overlap_ok(module):
             return
-        plan = self._plan(module)
-        for b in plan:
-            b["ready"], b["launched"] = 0, False
-            for p in b["params"]:
-                def hook(param, b=b):
-                    b["ready"] += 1
-                    if b["ready"] == len(b["params"]) and not b["launched"]:
-                        self._fill(b)
-                        self._launch(b)
-                self._hooks.append(p.register_post_accumulate_grad_hook(hook))
+        for b in self._plan(module):
+            b["ready"], b["launched"], b["armed"] = 0, False, True
 
     # ---------------------------------------------------------------- finish
     def __call__(self, modules):
-        for h in self._hooks:
-            h.remove()
-        self._hooks = []
         if not self.active:
             return
+        for m in modules:
+            for b in self._plan(m):
+                b["armed"] = False
         for m in modules:
             for b in self._plan(m):
                 if not b["launched"]:
