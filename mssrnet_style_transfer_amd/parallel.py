@@ -23,15 +23,17 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, always=False):
-        """``always``: issue the collectives even for a single rank (an identity reduction), which lets one GPU
+    def __init__(self, world_size=None, bucket_bytes=32 << 20, group=None, always=False, hook_min_numel=4096):
+        """``hook_min_numel``: matrices of at least this many elements are reduced from gradient hooks while the
+        backward runs; everything smaller waits for the final sync (see _plan).
+        ``always``: issue the collectives even for a single rank (an identity reduction), which lets one GPU
         exercise the RCCL path end to end -- hooks, side stream, async handles -- as the multi-GPU job will run it."""
         self.group = group
         self.world = world_size if world_size is not None else (dist.get_world_size(group)
                                                                  if dist.is_initialized() else 1)
         self.active = self.world > 1 or (always and dist.is_initialized())
         self.bucket_bytes = int(bucket_bytes)
-        self.hook_min_numel = 4096
+        self.hook_min_numel = int(hook_min_numel)
         self._plans = {}        # id(module) -> list of buckets
         self._pending = []      # (bucket, work handle)
         self._hooks = []

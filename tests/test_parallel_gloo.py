@@ -32,7 +32,8 @@ def _worker(rank, world, port, out):
     res = {}
     for mode in ("plain", "armed"):
         net = _net()
-        sync = GradSync(world, bucket_bytes=2048)      # tiny buckets -> several collectives
+        # tiny buckets -> several collectives; the two larger matrices are hooked, the rest waits for the final sync
+        sync = GradSync(world, bucket_bytes=2048, hook_min_numel=256)
         torch.manual_seed(100 + rank)
         x1, x2 = torch.randn(8, 16), torch.randn(8, 16)
         body = net[:5]
@@ -41,6 +42,8 @@ def _worker(rank, world, port, out):
             sync.arm(net)
         body(x2).sum().backward()                      # last backward (overlapped when armed)
         local = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        early = len(sync._pending)                     # collectives already launched from gradient hooks
+        assert early == (2 if mode == "armed" else 0), (mode, early)
         sync([net])
         res[mode] = (local, [None if p.grad is None else p.grad.clone() for p in net.parameters()])
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
