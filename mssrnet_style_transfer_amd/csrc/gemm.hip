@@ -188,6 +188,12 @@ static inline int pick_tile(int64_t m, int64_t n, int64_t batch) {
 template <typename TI, typename TO>
 static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
     const int t = pick_tile(a.m, a.n, batch);
+    // MSSR_GEMM_LOG=1: one stderr line per launch of this (general) kernel -- which problems miss the K-split kernel
+    static const bool log_shapes = getenv("MSSR_GEMM_LOG") != nullptr;
+    if (log_shapes)
+        fprintf(stderr, "mssr_gemm general tile=%d m=%lld n=%lld k=%lld batch=%lld a_cs=%lld b_rs=%lld in=%d out=%d\n", t,
+                (long long)a.m, (long long)a.n, (long long)a.k, (long long)batch, (long long)a.a_cs, (long long)a.b_rs,
+                (int)sizeof(TI), (int)sizeof(TO));
     if (t == 128128) {
         dim3 grid((unsigned)((a.n + 127) / 128), (unsigned)((a.m + 127) / 128), (unsigned)batch);
         klaunch(gemm_kernel<TI, TO, 128, 128>, grid, dim3(GEMM_THREADS), 0, s, a);

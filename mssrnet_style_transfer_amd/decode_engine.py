@@ -118,11 +118,21 @@ class _Pack:
                 self.cs_gen = self.wg_gen.float().sum(-1).contiguous()
                 self.bf_gen = (wg32 @ self.lnF_b + self.b_gen).contiguous()
                 names += ["wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1"]
+            self.wt_ckv = self.w_ckv.view(NL, 2 * d, d).transpose(1, 2).contiguous()      # [NL, d, 2d]
         arr = (L.DecLayer * NL)()
         for l in range(NL):
             for name in names:
                 setattr(arr[l], name, getattr(self, name)[l].data_ptr())
         self.layers = arr
+        # The transposed copies double as the k-contiguous operand of dX = dY W on the MODULE path (the
+        # teacher-forced decoder of the same model in the reconstruct phase): ops._Matmul finds them by parameter.
+        for l in range(NL):
+            for idx, wt, lo in ((_WQ, self.wt_qkv, 0), (_WK, self.wt_qkv, d), (_WV, self.wt_qkv, 2 * d),
+                                (_WSO, self.wt_so, 0), (_WCQ, self.wt_cq, 0), (_WCO, self.wt_co, 0),
+                                (_W1, self.wt_1, 0), (_W2, self.wt_2, 0), (_WCK, self.wt_ckv, 0), (_WCV, self.wt_ckv, d)):
+                w_p = lp[l][idx]
+                if isinstance(w_p, torch.nn.Parameter):
+                    ops.register_transposed(w_p, wt[l][:, lo:lo + w_p.shape[0]])
 
 
 _pack_cache = {}
