@@ -154,6 +154,7 @@ def get_pack(model, params):
 
 def clear_pack_cache():
     _pack_cache.clear()
+    ops._wt_registry.clear()        # the registered transposed copies are views of the packs
 
 
 class _Spec:

@@ -26,6 +26,7 @@ def set_compute_dtype(dtype):
         raise ValueError("compute dtype must be float32 or bfloat16")
     _state["dtype"] = dtype
     _cast_cache.clear()
+    _wt_registry.clear()
 
 
 def compute_dtype():

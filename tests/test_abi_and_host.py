@@ -210,3 +210,31 @@ def test_module_surface_matches_the_reference_contract():
     dkeys = set(dec.state_dict().keys())
     assert "transformer_layers.0.context_attn.final_linear.bias" in dkeys and "transformer_layers.0.layer_norm_2.weight" in dkeys
     assert tuple(enc.state_dict()["embeddings.make_embedding.pe.pe"].shape) == (5000, 1, cfg.d_model)
+
+
+def test_transposed_weight_registry_follows_parameter_versions():
+    """ops.register_transposed / ops.transposed: a registered copy is handed out only while the parameter is the same
+    object, same storage, same version and same params_changed epoch, and only in the compute dtype it was made in."""
+    from mssrnet_style_transfer_amd import ops
+    ops.set_compute_dtype(torch.float32)
+    lin = torch.nn.Linear(6, 4)
+    w = lin.weight
+    assert ops.transposed(w) is None
+    ops.register_transposed(w, w.detach().t().contiguous())
+    assert torch.equal(ops.transposed(w), w.detach().t())
+    with torch.no_grad():
+        w.mul_(2.0)                                        # in-place update bumps _version
+    assert ops.transposed(w) is None
+    ops.register_transposed(w, w.detach().t().contiguous())
+    assert ops.transposed(w) is not None
+    ops.params_changed(lin)                                # fused optimizers: the trainer's explicit signal
+    assert ops.transposed(w) is None
+    ops.register_transposed(w, w.detach().t().contiguous())
+    w.data = w.data.clone()                                # new storage (e.g. module.to / load into new tensors)
+    assert ops.transposed(w) is None
+    ops.register_transposed(w, w.detach().t().contiguous())
+    ops.set_compute_dtype(torch.bfloat16)                  # copies of another compute dtype are dropped
+    try:
+        assert ops.transposed(w) is None
+    finally:
+        ops.set_compute_dtype(torch.float32)
