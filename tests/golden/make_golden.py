@@ -582,8 +582,69 @@ def gen_greedy():
                 src=src, lens=lens, desired=desired)
 
 
+# ------------------------------------------------------------------------ flops
+def gen_flops():
+    """Algorithmic GEMM work of each phase: 2*M*N*K per matmul / bmm / addmm as counted by
+    torch.utils.flop_counter's formulas (the ones FlopCounterMode applies) over the REFERENCE trainer on the bench's synthetic batch, for the small
+    parity config and for configs[1] (12L d512, bs80, <=16 words, V=9606); the oracle port is counted next to it
+    (written to tests/golden/flops.json, plain JSON)."""
+    import json
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils.flop_counter import flop_registry
+    from oracle import phases as PH
+
+    class GemmFlops(TorchDispatchMode):
+        """FlopCounterMode's own per-op formulas (flop_registry) without its module tracker, whose multi-grad hooks
+        reject the autograd.grad calls of the gradient penalties."""
+
+        def __init__(self):
+            super().__init__()
+            self.total = 0
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            out = func(*args, **kwargs)
+            formula = flop_registry.get(func._overloadpacket)
+            if formula is not None:
+                self.total += int(formula(*args, **kwargs, out_val=out))
+            return out
+
+    def count(fn):
+        with GemmFlops() as fc:
+            fn()
+        return fc.total
+
+    out = {"_meta": dict(torch=str(torch.__version__), unit="GEMM FLOPs (2*M*N*K), one call of the phase",
+                         note="reference = /root/reference trainer under FlopCounterMode; oracle = oracle/phases.py")}
+    phases = ("train_discriminator", "train_generator", "train_reconstruct")
+    for tag, cfg, B, words, seed in (("small_b6_w7", MSSRConfig.small(), 6, 7, 9), ("configs1_b80_w16", MSSRConfig(), 80, 16, 123)):
+        batch = make_batch(B, words, cfg.vocab_size, seed=seed)
+        rbatch = SimpleNamespace(src=(batch.src, batch.src_lengths), tgt=batch.tgt, batch_size=batch.batch_size)
+        entry = {"batch": B, "max_words": words, "vocab": cfg.vocab_size, "tokens": int(batch.n_tokens)}
+        for fn in phases:
+            nets = build_ref_nets(cfg, 300)
+            states = {k: sd(m) for k, m in nets.items()}
+            tr = ref_trainer(cfg, nets)
+            torch.manual_seed(7)
+            random.seed(7)
+            ref = count(lambda: getattr(tr, fn)(rbatch))
+            onets = PH.make_nets(states, cfg)
+            torch.manual_seed(7)
+            random.seed(7)
+            orc = count(lambda: getattr(PH, fn)(onets, batch, cfg))
+            entry[fn] = {"reference": ref, "oracle": orc}
+            print(tag, fn, "reference %.3f GFLOP, oracle %.3f GFLOP" % (ref / 1e9, orc / 1e9), flush=True)
+        out[tag] = entry
+    path = os.path.join(HERE, "flops.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 def main():
     os.makedirs("/tmp/mssr_golden", exist_ok=True)
+    if sys.argv[1:] == ["flops"]:
+        return gen_flops()
     which = sys.argv[1:] or ["ops", "modules", "phases", "greedy"]
     meta = dict(torch=str(torch.__version__), note="generated from /root/reference by tests/golden/make_golden.py")
     for name in which:

@@ -321,3 +321,39 @@ def test_greedy(golden_phases, golden_greedy):
     preds = PH.greedy_decode(nets, golden_greedy["src"], golden_greedy["lens"], golden_greedy["desired"], cfg,
                              golden_greedy["max_length"])
     assert preds == golden_greedy["predictions"]
+
+
+def test_phase_gemm_work_matches_the_reference_count(golden_phases):
+    """SURVEY 8d's algorithmic work: GEMM FLOPs (2*M*N*K, torch.utils.flop_counter's formulas) of each phase.
+    tests/golden/flops.json holds the count over the REFERENCE trainer; the oracle, counted live on the small config,
+    must do exactly that work, and the recorded bs80 counts (configs[1], what bench.py's `algorithmic` field uses)
+    must agree between reference and oracle."""
+    import json
+    import os
+    from torch.utils._python_dispatch import TorchDispatchMode
+    from torch.utils.flop_counter import flop_registry
+
+    class GemmFlops(TorchDispatchMode):
+        total = 0
+
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            kwargs = kwargs or {}
+            out = func(*args, **kwargs)
+            formula = flop_registry.get(func._overloadpacket)
+            if formula is not None:
+                self.total += int(formula(*args, **kwargs, out_val=out))
+            return out
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "flops.json")) as f:
+        rec = json.load(f)
+    cfg = MSSRConfig.small()
+    small = rec["small_b6_w7"]
+    for fn in ("train_discriminator", "train_generator", "train_reconstruct"):
+        nets = PH.make_nets(golden_phases["init"], cfg)
+        torch.manual_seed(7)
+        random.seed(7)
+        with GemmFlops() as fc:
+            getattr(PH, fn)(nets, _batch(golden_phases), cfg)
+        assert fc.total == small[fn]["reference"], (fn, fc.total, small[fn])
+        full = rec["configs1_b80_w16"][fn]
+        assert full["reference"] == full["oracle"] and full["reference"] > 1e11, (fn, full)
