@@ -641,10 +641,50 @@ def gen_flops():
     print("wrote", path)
 
 
+def time_reference():
+    """SURVEY 8d 'CPU reference timing': the IMPORTED reference trainer and the oracle port timed side by side on this
+    container's host cores (fp32, training-mode dropout, 1 warm-up + 3 timed calls per phase) on the bench's bs80
+    batch -> profiles/r01_reference_cpu.json.  The reference cannot travel to the GPU box; this shows what the port
+    that bench.py times there (`cpu_baseline`, kind "port") stands for."""
+    import json
+    import time
+    from oracle import phases as PH
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    cfg = MSSRConfig()
+    batch = make_batch(80, 16, cfg.vocab_size, seed=123)
+    rbatch = SimpleNamespace(src=(batch.src, batch.src_lengths), tgt=batch.tgt, batch_size=batch.batch_size)
+    nets = build_ref_nets(cfg, 300)
+    states = {k: sd(m) for k, m in nets.items()}
+    tr = ref_trainer(cfg, nets)
+    onets = PH.make_nets(states, cfg)
+    out = {"_meta": dict(torch=str(torch.__version__), threads=threads, batch=80, max_words=16,
+                         tokens_per_step=int(batch.n_tokens), timing="1 warm-up + 3 timed calls, mean seconds")}
+    for fn in ("train_discriminator", "train_generator", "train_reconstruct"):
+        row = {}
+        for tag, call in (("reference", lambda: getattr(tr, fn)(rbatch)), ("oracle", lambda: getattr(PH, fn)(onets, batch, cfg))):
+            call()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                call()
+            row[tag] = round((time.perf_counter() - t0) / 3, 3)
+        out[fn] = row
+        print(fn, row, flush=True)
+    step = {k: out["train_discriminator"][k] + out["train_generator"][k] for k in ("reference", "oracle")}
+    out["wgan_step_tokens_per_s"] = {k: round(batch.n_tokens / v, 1) for k, v in step.items()}
+    print(out["wgan_step_tokens_per_s"])
+    path = os.path.join(os.path.dirname(os.path.dirname(HERE)), "profiles", "r01_reference_cpu.json")
+    with open(path, "w") as f:
+        json.dump(out, f, indent=1)
+    print("wrote", path)
+
+
 def main():
     os.makedirs("/tmp/mssr_golden", exist_ok=True)
     if sys.argv[1:] == ["flops"]:
         return gen_flops()
+    if sys.argv[1:] == ["reftime"]:
+        return time_reference()
     which = sys.argv[1:] or ["ops", "modules", "phases", "greedy"]
     meta = dict(torch=str(torch.__version__), note="generated from /root/reference by tests/golden/make_golden.py")
     for name in which:
