@@ -42,8 +42,8 @@ struct AttnArgs {
 
 __device__ __forceinline__ float fa_keep(const AttnArgs& a, int bh, int i, int t) {
     if (a.p_drop <= 0.f) return 1.0f;
-    const uint32_t thr = (uint32_t)((double)a.p_drop * 4294967296.0);
-    return hash_u32(a.seed, ((uint64_t)bh * a.Lq + i) * FA_MAXL + t) >= thr ? 1.0f / (1.0f - a.p_drop) : 0.f;
+    const uint32_t thr = drop_thr16(a.p_drop);
+    return keep16(a.seed, ((uint64_t)bh * a.Lq + i) * FA_MAXL + t, thr) ? 1.0f / (1.0f - a.p_drop) : 0.f;
 }
 
 // stage rows [0, n) of a [n, dh] head slice (row stride ls) into an LDS tile with row stride dh + pad

@@ -126,6 +126,21 @@ __device__ __forceinline__ uint32_t hash_u32(uint64_t seed, uint64_t idx) {
     return mix_u32((uint32_t)idx ^ s ^ ((hi << 16) | (hi >> 16)));
 }
 
+// Dropout decisions come in PAIRS: elements 2i and 2i+1 share one hash, 16 bits each against a 16-bit threshold (p is
+// quantised to 1/65536: 0.1 -> 0.09999).  The hash's two quarter-rate 32-bit multiplies dominate the integer work of
+// the kernels that replay dropout (gemm_lnb_kernel: 76 v_mul_lo_u32 per lane before, 44 after); kernels that own
+// consecutive elements take both decisions of a pair from one hash (keep16_pair), the others use keep16 - same decisions.
+__device__ __forceinline__ uint32_t drop_thr16(float p) { return (uint32_t)((double)p * 65536.0); }
+__device__ __forceinline__ bool keep16(uint64_t seed, uint64_t idx, uint32_t thr16) {
+    const uint32_t h = hash_u32(seed, idx >> 1);
+    return ((idx & 1) ? (h >> 16) : (h & 0xFFFFu)) >= thr16;
+}
+// both decisions of the pair (2 idx2, 2 idx2 + 1): bit 0 and bit 1 of the result
+__device__ __forceinline__ uint32_t keep16_pair(uint64_t seed, uint64_t idx2, uint32_t thr16) {
+    const uint32_t h = hash_u32(seed, idx2);
+    return ((h & 0xFFFFu) >= thr16 ? 1u : 0u) | ((h >> 16) >= thr16 ? 2u : 0u);
+}
+
 inline bool aligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 inline bool valid_dtype(int d) { return d == MSSR_F32 || d == MSSR_BF16; }
 inline size_t dsize(int d) { return d == MSSR_BF16 ? 2 : 4; }

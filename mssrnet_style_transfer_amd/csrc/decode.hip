@@ -73,10 +73,10 @@ __global__ __launch_bounds__(256) void attn_step_fwd_kernel(
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    const uint32_t thr = drop_thr16(p_drop);
     for (int t = lane; t < Lk; t += 64) {
         float p = s[t] * inv;
-        if (p_drop > 0.f) p = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? p * keep_scale : 0.f;
+        if (p_drop > 0.f) p = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? p * keep_scale : 0.f;
         s[t] = p;
     }
     __syncthreads();
@@ -162,13 +162,13 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    const uint32_t thr = drop_thr16(p_drop);
     // dp_t = m_t * sum_j dctx_j V[t][j] ; r = sum_t p_t dp_t
     float r = 0.f;
     for (int t = lane; t < Lk; t += 64) {
         const float p = s[t] * inv;
         float m = 1.0f;
-        if (p_drop > 0.f) m = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? keep_scale : 0.f;
+        if (p_drop > 0.f) m = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? keep_scale : 0.f;
         const T* vr = vp + (int64_t)t * kv_ts;
         float a = 0.f;
         for (int j = 0; j < dh; j += 4) {
@@ -394,10 +394,10 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    const uint32_t thr = drop_thr16(p_drop);
     for (int t = lane; t < Lk; t += 64) {
         float p = s[t] * inv;
-        if (p_drop > 0.f) p = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? p * keep_scale : 0.f;
+        if (p_drop > 0.f) p = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? p * keep_scale : 0.f;
         s[t] = p;
     }
     wave_lds_sync();
@@ -513,12 +513,12 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t thr = (uint32_t)((double)p_drop * 4294967296.0);
+    const uint32_t thr = drop_thr16(p_drop);
     float rr = 0.f;
     for (int t = lane; t < Lk; t += 64) {
         const float p = s[t] * inv;
         float m = 1.0f;
-        if (p_drop > 0.f) m = hash_u32(seed, (uint64_t)bh * AT_MAXK + t) >= thr ? keep_scale : 0.f;
+        if (p_drop > 0.f) m = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? keep_scale : 0.f;
         const float dp = dpv[t] * m;
         s[t] = p;
         dpv[t] = dp;
@@ -614,17 +614,22 @@ __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict
                                                              T* __restrict__ out, int rows, int d, int step, float s,
                                                              float p, uint64_t seed) {
     const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
-    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const uint32_t thr = drop_thr16(p);
     const int64_t n = (int64_t)rows * d;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
         const int c = (int)(i % d);
         float v[4], pp[4], o[4];
         V4<T>::load(e + i, v);
         V4<float>::load(pe + (int64_t)step * d + c, pp);
+        uint32_t kp[2] = {3u, 3u};          // i is a multiple of 4: two whole decision pairs
+        if (p > 0.f) {
+            kp[0] = keep16_pair(seed, (uint64_t)i >> 1, thr);
+            kp[1] = keep16_pair(seed, ((uint64_t)i >> 1) + 1, thr);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float t = v[j] * s + pp[j];
-            o[j] = (p > 0.f) ? (hash_u32(seed, (uint64_t)(i + j)) >= thr ? t * sc : 0.f) : t;
+            o[j] = (p > 0.f) ? (((kp[j >> 1] >> (j & 1)) & 1u) ? t * sc : 0.f) : t;
         }
         V4<T>::store(out + i, o);
     }

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(EW_BLOCK) void dropout_fwd_kernel(const T* __restri
                                                                T* __restrict__ y, uint8_t* __restrict__ mask,
                                                                int64_t n, float p, uint64_t seed) {
     const float inv = 1.0f / (1.0f - p);
-    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const uint32_t thr = drop_thr16(p);
     const int64_t nv = n >> 2;
     const int64_t stride = (int64_t)gridDim.x * EW_BLOCK;
     for (int64_t i = (int64_t)blockIdx.x * EW_BLOCK + threadIdx.x; i < nv; i += stride) {
@@ -25,9 +25,10 @@ __global__ __launch_bounds__(EW_BLOCK) void dropout_fwd_kernel(const T* __restri
         V4<T>::load(x + i * 4, v);
         if (res) V4<T>::load(res + i * 4, r);
         uint32_t packed = 0;
+        const uint32_t kp[2] = {keep16_pair(seed, (uint64_t)i * 2, thr), keep16_pair(seed, (uint64_t)i * 2 + 1, thr)};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t keep = hash_u32(seed, (uint64_t)(i * 4 + j)) >= thr ? 1u : 0u;
+            const uint32_t keep = (kp[j >> 1] >> (j & 1)) & 1u;
             packed |= keep << (8 * j);
             o[j] = (keep ? v[j] * inv : 0.f) + r[j];
         }
@@ -37,7 +38,7 @@ __global__ __launch_bounds__(EW_BLOCK) void dropout_fwd_kernel(const T* __restri
     // tail (n % 4)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = (nv << 2) + threadIdx.x;
-        const bool keep = hash_u32(seed, (uint64_t)i) >= thr;
+        const bool keep = keep16(seed, (uint64_t)i, thr);
         mask[i] = keep ? 1 : 0;
         y[i] = from_f<T>((keep ? to_f(x[i]) * inv : 0.f) + (res ? to_f(res[i]) : 0.f));
     }

@@ -66,20 +66,26 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
     }
     const float c1 = wave_sum(s1) / (float)d, c2 = wave_sum(s2) / (float)d;
     const float sc = extra / (1.0f - p);
-    const uint32_t thr = (uint32_t)((double)p * 4294967296.0);
+    const uint32_t thr = drop_thr16(p);
     for (int c = lane * 4; c < d; c += 256) {
         float xv[4], dv[4], g[4], rr[4] = {0.f, 0.f, 0.f, 0.f}, o[4], o2[4];
         V4<T>::load(xr + c, xv);
         V4<T>::load(dr + c, dv);
         V4<float>::load(gamma + c, g);
         if (dres) V4<T>::load(dres + (int64_t)row * d + c, rr);
+        uint32_t kp[2] = {3u, 3u};          // row * d + c is a multiple of 4 (vector loads): two whole decision pairs
+        if (p > 0.f) {
+            const uint64_t i2 = ((uint64_t)row * d + c) >> 1;
+            kp[0] = keep16_pair(seed, i2, thr);
+            kp[1] = keep16_pair(seed, i2 + 1, thr);
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             o[j] = rr[j] + rs * (dv[j] * g[j] - c1 - (xv[j] - mu) * rs * c2);
             // the forward rounded nothing between dropout and the residual add, but dx IS stored in T:
             // replay from the stored value so that dx2 matches a separate pass over dx bit for bit
             const float ov = to_f(from_f<T>(o[j]));
-            o2[j] = (p > 0.f) ? (hash_u32(seed, (uint64_t)row * d + c + j) >= thr ? ov * sc : 0.f) : ov * extra;
+            o2[j] = (p > 0.f) ? (((kp[j >> 1] >> (j & 1)) & 1u) ? ov * sc : 0.f) : ov * extra;
         }
         V4<T>::store(dx + (int64_t)row * d + c, o);
         if (dx2) V4<T>::store(dx2 + (int64_t)row * d + c, o2);

@@ -43,7 +43,7 @@ struct GemmArgs {
 };
 
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
-    return hash_u32(seed, idx) >= (uint32_t)((double)p * 4294967296.0);
+    return keep16(seed, idx, drop_thr16(p));
 }
 
 // v = alpha*acc (+bias) ; relu ; dropout ; (+residual) ; gate ; (+beta*C_old)

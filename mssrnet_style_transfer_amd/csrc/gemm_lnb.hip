@@ -98,7 +98,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     const float c1 = ((stat[0][rl][0] + stat[1][rl][0]) + (stat[2][rl][0] + stat[3][rl][0])) / (float)p.k;
     const float c2 = ((stat[0][rl][1] + stat[1][rl][1]) + (stat[2][rl][1] + stat[3][rl][1])) / (float)p.k;
     const float sc = p.lnb_extra / (1.0f - p.lnb_p);
-    const uint32_t thr = (uint32_t)((double)p.lnb_p * 4294967296.0);
+    const uint32_t thr = drop_thr16(p.lnb_p);
     const bool writer = blockIdx.x == 0 && row_ok;
     f32x4 acc[LNB_FN];
 #pragma unroll
@@ -109,6 +109,12 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
         const bool live = sg < steps;
         const int64_t k = (live ? sg : steps - 1) * 32 + koff;
         bf16x8 dxv, dx2v;
+        uint32_t kp[4] = {3u, 3u, 3u, 3u};  // ar * K + k is a multiple of 8: four whole decision pairs
+        if (p.lnb_p > 0.f) {
+            const uint64_t i2 = (uint64_t)(ar * p.k + k) >> 1;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) kp[q] = keep16_pair(p.lnb_seed, i2 + q, thr);
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const float a = (float)fdy[g][j] * (j < 4 ? g0[g][j] : g1[g][j - 4]);
@@ -116,8 +122,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
             const float o = (has_res ? (float)fr[g][j] : 0.f) + rs * (a - c1 - xh * c2);
             const bf16 ob = (bf16)o;
             const float ov = (float)ob;               // dx IS stored in bf16: replay from the stored value
-            const float o2 = p.lnb_p > 0.f ? (hash_u32(p.lnb_seed, (uint64_t)(ar * p.k + k + j)) >= thr ? ov * sc : 0.f)
-                                            : ov * p.lnb_extra;
+            const float o2 = p.lnb_p > 0.f ? (((kp[j >> 1] >> (j & 1)) & 1u) ? ov * sc : 0.f) : ov * p.lnb_extra;
             dxv[j] = ob;
             dx2v[j] = (bf16)o2;
         }
