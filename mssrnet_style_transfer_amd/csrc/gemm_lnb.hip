@@ -9,21 +9,24 @@
 // one CU's load bandwidth does not.  Measured per launch (bs160, d = 512, dropout 0.1), against 5.4 + 4.4 us for the
 // two separate kernels plus ~1.3 us of kernel boundary: 16x16 tiles 11.8 us, 16x32 9.3, 16x64 9.8, 16x128 12.5.
 // The 16x32 tile is kept: ~1 % of the WGAN step.  All loads (dy, x, dres, gamma, W) are issued before the first use.
+// Waves per block (same tile, K split over the waves): 4 -> 8.9 ms per WGAN step in this kernel, 8 -> 8.3 (two waves
+// per SIMD overlap their load -> reduce -> MFMA chains), 16 -> 9.3; 8 waves with 16x64 tiles 8.4.
 #include "gemm_common.hpp"
 #include <initializer_list>
 
 namespace mssr {
 
 typedef unsigned lnb_u32x4 __attribute__((ext_vector_type(4)));
-constexpr int LNB_THREADS = 256;
+constexpr int LNB_NW = 8;                  // waves per block (two per SIMD: one wave's load / reduce chain hides the other's)
+constexpr int LNB_THREADS = 64 * LNB_NW;
 constexpr int LNB_FN = 2;                  // 16-column fragments per block tile (see the measurements above)
 constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
-constexpr int LNB_G = 4;                   // k-steps per wave (K <= 4 waves * 4 * 32 = 512)
+constexpr int LNB_G = 2;                   // k-steps per wave (K <= LNB_NW * LNB_G * 32 = 512)
 
 template <typename TO>
 __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4][16][LNB_TSN];
-    __shared__ float stat[4][16][2];
+    __shared__ __attribute__((aligned(16))) float red[LNB_NW][16][LNB_TSN];
+    __shared__ float stat[LNB_NW][16][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n0 = (int64_t)blockIdx.x * LNB_TSN, m0 = (int64_t)blockIdx.y * 16;
     const int64_t steps = p.k / 32;
@@ -44,14 +47,14 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
         wrow[j] = (wn < p.n ? wn : p.n - 1) * p.b_cs;
     }
     // epilogue operands of the elements this thread finishes (e = tid + i*256: row e / LNB_TSN, col e % LNB_TSN)
-    constexpr int EPT = 16 * LNB_TSN / LNB_THREADS;
+    constexpr int EPT = (16 * LNB_TSN + LNB_THREADS - 1) / LNB_THREADS;
     float gate[EPT];
     bool eok[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = threadIdx.x + i * LNB_THREADS;
         const int64_t erow = m0 + e / LNB_TSN, ecol = n0 + e % LNB_TSN;
-        eok[i] = erow < p.m && ecol < p.n;
+        eok[i] = e < 16 * LNB_TSN && erow < p.m && ecol < p.n;
         gate[i] = 1.f;
         if (eok[i] && p.gate) gate[i] = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol]);
     }
@@ -60,7 +63,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     f32x4 g0[LNB_G], g1[LNB_G];
 #pragma unroll
     for (int g = 0; g < LNB_G; ++g) {
-        int64_t s = wave + 4 * g;
+        int64_t s = wave + LNB_NW * g;
         s = s < steps ? s : steps - 1;
         const int64_t k = s * 32 + koff;
         fdy[g] = *reinterpret_cast<const bf16x8*>(DY + arow + k);
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int g = 0; g < LNB_G; ++g) {
-        if (wave + 4 * g < steps) {
+        if (wave + LNB_NW * g < steps) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const float a = (float)fdy[g][j] * (j < 4 ? g0[g][j] : g1[g][j - 4]);
@@ -95,8 +98,14 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     }
     __syncthreads();
     const int rl = lane & 15;
-    const float c1 = ((stat[0][rl][0] + stat[1][rl][0]) + (stat[2][rl][0] + stat[3][rl][0])) / (float)p.k;
-    const float c2 = ((stat[0][rl][1] + stat[1][rl][1]) + (stat[2][rl][1] + stat[3][rl][1])) / (float)p.k;
+    float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < LNB_NW; ++w) {
+        c1 += stat[w][rl][0];
+        c2 += stat[w][rl][1];
+    }
+    c1 /= (float)p.k;
+    c2 /= (float)p.k;
     const float sc = p.lnb_extra / (1.0f - p.lnb_p);
     const uint32_t thr = drop_thr16(p.lnb_p);
     const bool writer = blockIdx.x == 0 && row_ok;
@@ -105,7 +114,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     for (int j = 0; j < LNB_FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < LNB_G; ++g) {
-        const int64_t sg = wave + 4 * g;
+        const int64_t sg = wave + LNB_NW * g;
         const bool live = sg < steps;
         const int64_t k = (live ? sg : steps - 1) * 32 + koff;
         bf16x8 dxv, dx2v;
@@ -137,7 +146,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
 #pragma unroll
         for (int j = 0; j < LNB_FN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, fb[g][j], acc[j], 0, 0, 0);
     }
-    // partial tiles of the 4 waves -> LDS (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
+    // partial tiles of the waves -> LDS (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
 #pragma unroll
     for (int j = 0; j < LNB_FN; ++j)
 #pragma unroll
@@ -149,7 +158,9 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
         if (!eok[i]) continue;
         const int e = threadIdx.x + i * LNB_THREADS;
         const int rr = e / LNB_TSN, cc = e % LNB_TSN;
-        float v = (red[0][rr][cc] + red[1][rr][cc]) + (red[2][rr][cc] + red[3][rr][cc]);
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < LNB_NW; ++w) v += red[w][rr][cc];
         v *= p.alpha;
         if (p.gate) v = gate[i] > 0.f ? v : 0.f;
         C[(m0 + rr) * p.ldc + n0 + cc] = from_f<TO>(v);
@@ -159,7 +170,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
 bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s) {
     if (!a.lnb_x || !a.lnb_gamma || !a.lnb_mean || !a.lnb_rstd || !a.lnb_dx) return false;
     if (a.bias || a.residual || a.relu || a.drop_p > 0.f || a.beta != 0.f || a.ln_colsum) return false;   // plain epilogue (+ gate)
-    if (a.m < 1 || a.n < 1 || a.k < 32 || a.k % 32 != 0 || a.k > 4 * LNB_G * 32) return false;
+    if (a.m < 1 || a.n < 1 || a.k < 32 || a.k % 32 != 0 || a.k > LNB_NW * LNB_G * 32) return false;
     if (a.a_cs != 1 || a.b_rs != 1 || a.a_rs % 8 != 0 || a.b_cs % 8 != 0) return false;
     if ((a.m + 15) / 16 > 65535) return false;
     if (a.lnb_dres == a.lnb_dx) return false;
