@@ -16,6 +16,7 @@ a parameter's version changes (i.e. after an optimizer step).
 import ctypes
 import math
 import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -138,18 +139,42 @@ class _Pack:
 _pack_cache = {}
 
 
+def _pack_version(cd, params):
+    """What a cached pack was built from: compute dtype, every parameter's in-place version, the
+    ``ops.params_changed`` epochs (fused optimizers do not bump ``_version``) and EVERY parameter's
+    storage address (``module.to`` / ``load_state_dict`` into fresh tensors, or another model that
+    happens to sit at a recycled ``id``)."""
+    return (cd, tuple(p._version for p in params), sum(ops.param_epoch(p) for p in params),
+            tuple(p.data_ptr() for p in params))
+
+
+def cached_pack(cache, owner, params, build):
+    """``build()`` once per (owner object, parameter versions).  Entries are keyed by ``id(owner)`` but
+    only trusted while the weak reference stored beside them still resolves to ``owner`` itself, and
+    they are dropped (with the GPU memory of the pack) when the owner is garbage collected."""
+    ver = _pack_version(ops.compute_dtype(), params)
+    key = id(owner)
+    hit = cache.get(key)
+    if hit is not None and hit[2]() is owner and hit[0] == ver:
+        return hit[1]
+    pack = build()
+    ref = weakref.ref(owner)
+    cache[key] = (ver, pack, ref)
+
+    def _evict(cache=cache, key=key, ref=ref):
+        held = cache.get(key)
+        if held is not None and held[2] is ref:
+            del cache[key]
+
+    weakref.finalize(owner, _evict)
+    return pack
+
+
 def get_pack(model, params):
     """The packed weights of ``model``'s decoder, rebuilt when any parameter changed in place."""
     cd = ops.compute_dtype()
-    key = id(model)
-    ver = (cd, tuple(p._version for p in params), sum(ops.param_epoch(p) for p in params),
-           tuple(p.data_ptr() for p in params[:2]))
-    hit = _pack_cache.get(key)
-    if hit is not None and hit[0] == ver:
-        return hit[1]
-    pack = _Pack(params, len(model.decoder.transformer_layers), cd)
-    _pack_cache[key] = (ver, pack)
-    return pack
+    return cached_pack(_pack_cache, model, params,
+                       lambda: _Pack(params, len(model.decoder.transformer_layers), cd))
 
 
 def clear_pack_cache():

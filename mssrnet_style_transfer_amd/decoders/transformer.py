@@ -1,11 +1,19 @@
 """Transformer decoder on the gfx950 kernels.
 
-Drop-in for onmt/decoders/transformer.py:14-357: ``TransformerDecoderLayer`` (attributes
-``self_attn, context_attn, feed_forward, layer_norm_1, layer_norm_2, drop``) and
-``TransformerDecoder`` (``embeddings, state, transformer_layers, layer_norm``;
-``init_state / map_state / detach_state / forward(tgt, memory_bank, step=None,
-memory_lengths=...) -> (dec_outs [T,B,d], {"std": attn [T,B,L]})``) including the step-wise
-``state["cache"]["layer_i"]`` dict protocol used by the soft decode and by greedy search.
+Drop-in for the two classes of onmt/decoders/transformer.py:14-357.  What the reference's callers
+rely on, and therefore what is kept: the class names, the constructor argument order, the
+attribute names that end up in checkpoints (``self_attn, context_attn, feed_forward,
+layer_norm_1, layer_norm_2, drop`` per layer; ``embeddings, transformer_layers, layer_norm``
+on the decoder), the ``state`` dict with its ``"src"`` entry and the per-layer
+``state["cache"]["layer_i"]`` dicts that MultiHeadedAttention fills, and
+``forward(tgt, memory_bank, step=None, memory_lengths=...) -> (dec_outs [T,B,d],
+{"std": attn [T,B,L]})``.
+
+What MSSRNet never turns on is NOT carried over: guided alignment (``with_align``,
+``full_context_alignment``, ``alignment_heads``, ``lambda_align = 0`` in every README config) and the
+copy-attention output.  The constructor still accepts and records those arguments (they are part of
+the pickled attribute set) and a call that asks for them fails loudly instead of silently
+returning something else.
 """
 import torch
 import torch.nn as nn
@@ -16,8 +24,22 @@ from ..modules.position_ffn import PositionwiseFeedForward
 from ..utils.misc import sequence_mask
 from .decoder import DecoderBase
 
+_CACHE_SLOTS = ("memory_keys", "memory_values", "self_keys", "self_values")
+
+
+def _first(value):
+    """OpenNMT options hold dropout rates as one-element lists."""
+    return value[0] if isinstance(value, list) else value
+
+
+def _norm(ln, x):
+    return ops.layer_norm(x, ln.weight, ln.bias, ln.eps)
+
 
 class TransformerDecoderLayer(nn.Module):
+    """Pre-norm decoder layer: x + D(self-attn(LN1 x)) -> h + D(ctx-attn(LN2 h)) -> FFN
+    (onmt/decoders/transformer.py:110-171)."""
+
     def __init__(self, d_model, heads, d_ff, dropout, attention_dropout, self_attn_type="scaled-dot",
                  max_relative_positions=0, aan_useffn=False, full_context_alignment=False, alignment_heads=0):
         super().__init__()
@@ -30,48 +52,43 @@ class TransformerDecoderLayer(nn.Module):
         self.layer_norm_1 = nn.LayerNorm(d_model, eps=1e-6)
         self.layer_norm_2 = nn.LayerNorm(d_model, eps=1e-6)
         self.drop = nn.Dropout(dropout)
+        # recorded only: the alignment branches of the reference (:96-107) are not reproduced
         self.full_context_alignment = full_context_alignment
         self.alignment_heads = alignment_heads
 
-    def forward(self, *args, **kwargs):
-        """Returns (output [B,T,d], top_attn [B,T,L] = head 0 of the context attention, attn_align)."""
-        with_align = kwargs.pop("with_align", False)
-        output, attns = self._forward(*args, **kwargs)
-        top_attn = attns[:, 0, :, :].contiguous()
-        attn_align = None
-        if with_align:
-            if self.full_context_alignment:
-                _, attns = self._forward(*args, **kwargs, future=True)
-            if self.alignment_heads > 0:
-                attns = attns[:, :self.alignment_heads, :, :].contiguous()
-            attn_align = attns.mean(dim=1)
-        return output, top_attn, attn_align
+    def _self_mask(self, tgt_pad_mask, step):
+        """Causal + target-padding mask for a whole sequence; None while decoding step by step, where
+        the cache holds only the past (reference :132-149)."""
+        if step is not None:
+            return None
+        T = tgt_pad_mask.size(-1)
+        causal = torch.ones(T, T, dtype=torch.bool, device=tgt_pad_mask.device).triu_(1)
+        return tgt_pad_mask | causal.unsqueeze(0)
 
-    def _forward(self, inputs, memory_bank, src_pad_mask, tgt_pad_mask, layer_cache=None, step=None,
-                 future=False):
-        dec_mask = None
-        if step is None:
-            tgt_len = tgt_pad_mask.size(-1)
-            if not future:
-                future_mask = torch.ones([tgt_len, tgt_len], device=tgt_pad_mask.device,
-                                         dtype=torch.bool).triu_(1).view(1, tgt_len, tgt_len)
-                dec_mask = tgt_pad_mask | future_mask
-            else:
-                dec_mask = tgt_pad_mask
-        ln1, ln2 = self.layer_norm_1, self.layer_norm_2
-        input_norm = ops.layer_norm(inputs, ln1.weight, ln1.bias, ln1.eps)
-        query, _ = self.self_attn(input_norm, input_norm, input_norm, mask=dec_mask, layer_cache=layer_cache,
-                                  attn_type="self")
-        query = ops.dropout(query, self.drop.p, self.training, residual=inputs)
-        query_norm = ops.layer_norm(query, ln2.weight, ln2.bias, ln2.eps)
-        mid, attns = self.context_attn(memory_bank, memory_bank, query_norm, mask=src_pad_mask,
-                                       layer_cache=layer_cache, attn_type="context")
-        output = self.feed_forward(ops.dropout(mid, self.drop.p, self.training, residual=query))
-        return output, attns
+    def _forward(self, inputs, memory_bank, src_pad_mask, tgt_pad_mask, layer_cache=None, step=None):
+        """(output [B,T,d], context-attention probabilities [B,H,T,L])."""
+        p, training = self.drop.p, self.training
+        x1 = _norm(self.layer_norm_1, inputs)
+        sa, _ = self.self_attn(x1, x1, x1, mask=self._self_mask(tgt_pad_mask, step), layer_cache=layer_cache,
+                               attn_type="self")
+        h = ops.dropout(sa, p, training, residual=inputs)
+        ca, probs = self.context_attn(memory_bank, memory_bank, _norm(self.layer_norm_2, h), mask=src_pad_mask,
+                                      layer_cache=layer_cache, attn_type="context")
+        return self.feed_forward(ops.dropout(ca, p, training, residual=h)), probs
+
+    def forward(self, inputs, memory_bank, src_pad_mask, tgt_pad_mask, layer_cache=None, step=None,
+                with_align=False):
+        """(output, head 0 of the context attention [B,T,L], None) -- reference :75-108 with the
+        alignment head always absent."""
+        if with_align:
+            raise NotImplementedError("guided alignment (with_align) is not part of the MSSRNet path")
+        out, probs = self._forward(inputs, memory_bank, src_pad_mask, tgt_pad_mask, layer_cache=layer_cache,
+                                   step=step)
+        return out, probs[:, 0].contiguous(), None
 
     def update_dropout(self, dropout, attention_dropout):
-        self.self_attn.update_dropout(attention_dropout)
-        self.context_attn.update_dropout(attention_dropout)
+        for attn in (self.self_attn, self.context_attn):
+            attn.update_dropout(attention_dropout)
         self.feed_forward.update_dropout(dropout)
         self.drop.p = dropout
 
@@ -83,85 +100,69 @@ class TransformerDecoder(DecoderBase):
         super().__init__()
         self.embeddings = embeddings
         self.state = {}
-        self.transformer_layers = nn.ModuleList(
-            [TransformerDecoderLayer(d_model, heads, d_ff, dropout, attention_dropout,
-                                     self_attn_type=self_attn_type,
-                                     max_relative_positions=max_relative_positions, aan_useffn=aan_useffn,
-                                     full_context_alignment=full_context_alignment,
-                                     alignment_heads=alignment_heads)
-             for _ in range(num_layers)])
-        self._copy = copy_attn
+        layers = []
+        for _ in range(num_layers):
+            layers.append(TransformerDecoderLayer(
+                d_model, heads, d_ff, dropout, attention_dropout, self_attn_type=self_attn_type,
+                max_relative_positions=max_relative_positions, aan_useffn=aan_useffn,
+                full_context_alignment=full_context_alignment, alignment_heads=alignment_heads))
+        self.transformer_layers = nn.ModuleList(layers)
         self.layer_norm = nn.LayerNorm(d_model, eps=1e-6)
-        self.alignment_layer = alignment_layer
+        self._copy = copy_attn                  # recorded only (no copy generator on this path)
+        self.alignment_layer = alignment_layer  # recorded only
 
     @classmethod
     def from_opt(cls, opt, embeddings):
-        return cls(opt.dec_layers, opt.dec_rnn_size, opt.heads, opt.transformer_ff, opt.copy_attn,
-                   opt.self_attn_type,
-                   opt.dropout[0] if type(opt.dropout) is list else opt.dropout,
-                   opt.attention_dropout[0] if type(opt.attention_dropout) is list else opt.attention_dropout,
-                   embeddings, opt.max_relative_positions, opt.aan_useffn, opt.full_context_alignment,
-                   opt.alignment_layer, alignment_heads=opt.alignment_heads)
+        """Reads the same option names as the reference's from_opt (:249-266)."""
+        return cls(num_layers=opt.dec_layers, d_model=opt.dec_rnn_size, heads=opt.heads, d_ff=opt.transformer_ff,
+                   copy_attn=opt.copy_attn, self_attn_type=opt.self_attn_type, dropout=_first(opt.dropout),
+                   attention_dropout=_first(opt.attention_dropout), embeddings=embeddings,
+                   max_relative_positions=opt.max_relative_positions, aan_useffn=opt.aan_useffn,
+                   full_context_alignment=opt.full_context_alignment, alignment_layer=opt.alignment_layer,
+                   alignment_heads=opt.alignment_heads)
 
+    # ---- decoding state: {"src": [Ls,B,1] ids, "cache": {"layer_i": {four tensors [B,H,len,dh]}} | None}
     def init_state(self, src, memory_bank, enc_hidden):
         self.state["src"] = src
         self.state["cache"] = None
 
-    def map_state(self, fn):
-        def _recursive_map(struct, batch_dim=0):
-            for k, v in struct.items():
-                if v is not None:
-                    if isinstance(v, dict):
-                        _recursive_map(v)
-                    else:
-                        struct[k] = fn(v, batch_dim)
+    def _init_cache(self, memory_bank):
+        self.state["cache"] = {"layer_%d" % i: dict.fromkeys(_CACHE_SLOTS)
+                               for i in range(len(self.transformer_layers))}
 
+    def map_state(self, fn):
+        """Applies ``fn(tensor, batch_dim)`` to the source ids (batch on dim 1) and to every cached
+        key / value tensor (batch on dim 0): how greedy search drops finished sentences
+        (onmt/translate/translator_wh.py:744-746)."""
         self.state["src"] = fn(self.state["src"], 1)
-        if self.state["cache"] is not None:
-            _recursive_map(self.state["cache"])
+        for layer_cache in (self.state["cache"] or {}).values():
+            for slot, held in layer_cache.items():
+                if held is not None:
+                    layer_cache[slot] = fn(held, 0)
 
     def detach_state(self):
         self.state["src"] = self.state["src"].detach()
 
-    def forward(self, tgt, memory_bank, step=None, **kwargs):
+    def forward(self, tgt, memory_bank, step=None, memory_lengths=None, with_align=False, **unused):
+        """tgt: Long [T,B,1] ids or float [T,B,V] probabilities (one row when ``step`` is given)."""
+        if with_align:
+            raise NotImplementedError("guided alignment (with_align) is not part of the MSSRNet path")
         if step == 0:
             self._init_cache(memory_bank)
-        tgt_words = tgt[:, :, 0].transpose(0, 1)
-        emb = self.embeddings(tgt, step=step)
-        assert emb.dim() == 3
-        output = emb.transpose(0, 1).contiguous()
-        src_memory_bank = memory_bank.transpose(0, 1).contiguous()
-        pad_idx = self.embeddings.word_padding_idx
-        src_lens = kwargs["memory_lengths"]
-        src_max_len = self.state["src"].shape[0]
-        src_pad_mask = ~sequence_mask(src_lens, src_max_len).unsqueeze(1)
-        # float tgt (soft inputs): compares the probability of word 0 with pad_idx, as the reference does
-        tgt_pad_mask = tgt_words.detach().eq(pad_idx).unsqueeze(1)
-        with_align = kwargs.pop("with_align", False)
-        attn_aligns = []
-        attn = None
+        x = self.embeddings(tgt, step=step).transpose(0, 1).contiguous()          # [B,T,d]
+        memory = memory_bank.transpose(0, 1).contiguous()                          # [B,Ls,d]
+        # the source width comes from the ids given to init_state, as in the reference (:304)
+        src_pad = ~sequence_mask(memory_lengths, self.state["src"].shape[0]).unsqueeze(1)
+        # column 0 of a SOFT input is the probability of word 0: comparing it with the padding index
+        # reproduces the reference (:294,306), i.e. effectively no target padding mask on that path
+        tgt_pad = tgt[:, :, 0].t().detach().eq(self.embeddings.word_padding_idx).unsqueeze(1)
+        caches = self.state["cache"] if step is not None else None
+        top = None
         for i, layer in enumerate(self.transformer_layers):
-            layer_cache = self.state["cache"]["layer_{}".format(i)] if step is not None else None
-            output, attn, attn_align = layer(output, src_memory_bank, src_pad_mask, tgt_pad_mask,
-                                             layer_cache=layer_cache, step=step, with_align=with_align)
-            if attn_align is not None:
-                attn_aligns.append(attn_align)
-        ln = self.layer_norm
-        output = ops.layer_norm(output, ln.weight, ln.bias, ln.eps)
-        dec_outs = output.transpose(0, 1).contiguous()
-        attn = attn.transpose(0, 1).contiguous()
-        attns = {"std": attn}
-        if self._copy:
-            attns["copy"] = attn
-        if with_align:
-            attns["align"] = attn_aligns[self.alignment_layer]
-        return dec_outs, attns
-
-    def _init_cache(self, memory_bank):
-        self.state["cache"] = {}
-        for i, layer in enumerate(self.transformer_layers):
-            self.state["cache"]["layer_{}".format(i)] = {"memory_keys": None, "memory_values": None,
-                                                         "self_keys": None, "self_values": None}
+            x, top, _ = layer(x, memory, src_pad, tgt_pad, step=step,
+                              layer_cache=None if caches is None else caches["layer_%d" % i])
+        dec_outs = _norm(self.layer_norm, x).transpose(0, 1).contiguous()
+        return dec_outs, {"std": top.transpose(0, 1).contiguous()}
 
     def update_dropout(self, dropout, attention_dropout):
         self.embeddings.update_dropout(dropout)

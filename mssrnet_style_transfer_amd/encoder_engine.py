@@ -18,7 +18,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import ops
-from .decode_engine import _bgemm_t, _bsum
+from .decode_engine import _bgemm_t, _bsum, cached_pack
 
 N_ENC_LAYER_PARAMS = 16
 (_WQ, _BQ, _WK, _BK, _WV, _BV, _WO, _BO, _W1, _B1, _W2, _B2, _LNFG, _LNFB, _LN1G, _LN1B) = range(N_ENC_LAYER_PARAMS)
@@ -94,15 +94,7 @@ _pack_cache = {}
 
 def get_pack(enc, params):
     cd = ops.compute_dtype()
-    ver = (cd, tuple(p._version for p in params), sum(ops.param_epoch(p) for p in params),
-           tuple(p.data_ptr() for p in params[:3]))
-    hit = _pack_cache.get(id(enc))
-    if hit is not None and hit[0] == ver and hit[2]() is enc:
-        return hit[1]
-    import weakref
-    pack = _Pack(params, len(enc.transformer), cd)
-    _pack_cache[id(enc)] = (ver, pack, weakref.ref(enc))
-    return pack
+    return cached_pack(_pack_cache, enc, params, lambda: _Pack(params, len(enc.transformer), cd))
 
 
 class _Spec:
