@@ -68,6 +68,8 @@ class MSSRConfig:
     # not a reference flag: batch the independent style-generator / encoder / decode calls of the generator
     # phase (same weights, same source) into single calls; results equal up to summation order
     batch_generator_phase: bool = True
+    # not a reference flag: the style critic computes in fp32 even when the compute dtype is bf16
+    style_critic_fp32: bool = True
 
     @property
     def d_cls(self):

@@ -38,6 +38,29 @@ class PositionalEncoding(nn.Module):
         return ops.dropout(out, self.dropout.p, self.training)
 
 
+class VecEmbedding(nn.Module):
+    """Embedding of vector sequences [len, B, 1, vec_size] -> [len, B, emb_dim] (a bias-free projection, then the
+    positional encoding).  No MSSRNet configuration builds one (onmt/modules/embeddings.py:57-88 serves the
+    ``vec`` data type); it exists because ``onmt/modules/__init__.py:9-10`` imports the name from this module path."""
+
+    def __init__(self, vec_size, emb_dim, position_encoding=False, dropout=0):
+        super().__init__()
+        self.embedding_size = emb_dim
+        self.word_padding_idx = 0
+        self.position_encoding = position_encoding
+        self.proj = nn.Linear(vec_size, emb_dim, bias=False)
+        if position_encoding:
+            self.pe = PositionalEncoding(dropout, emb_dim)
+
+    def forward(self, x, step=None):
+        out = ops.linear(x.squeeze(2), self.proj.weight)
+        return self.pe(out, step=step) if self.position_encoding else out
+
+    def load_pretrained_vectors(self, file):
+        if file:
+            raise ValueError("VecEmbedding has no pretrained vectors to load")
+
+
 class Embeddings(nn.Module):
     def __init__(self, word_vec_size, word_vocab_size, word_padding_idx, position_encoding=False,
                  feat_merge="concat", feat_vec_exponent=0.7, feat_vec_size=-1, feat_padding_idx=None,

@@ -33,6 +33,40 @@ def compute_dtype():
     return _state["dtype"]
 
 
+class compute_as:
+    """Context manager: run the ops inside in ``dtype`` (an fp32 island inside a bf16 run, e.g. the small style
+    critic whose gradient-penalty double-backward loses too much to 8-bit mantissas).  Every op remembers the
+    compute dtype of its forward, and its backward -- first and second order, whenever and on whichever thread
+    autograd runs it -- computes in that dtype again (``_in_forward_dtype``).  Unlike ``set_compute_dtype`` nothing
+    is flushed: the weight caches are keyed by dtype."""
+
+    def __init__(self, dtype):
+        if dtype not in (torch.float32, torch.bfloat16):
+            raise ValueError("compute dtype must be float32 or bfloat16")
+        self.dtype = dtype
+
+    def __enter__(self):
+        self.prev = _state["dtype"]
+        _state["dtype"] = self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        _state["dtype"] = self.prev
+
+
+def _in_forward_dtype(backward):
+    """Decorator for Function.backward: compute in the dtype the forward ran in (ctx.cd)."""
+    def wrapped(ctx, *grads):
+        cd = getattr(ctx, "cd", None)
+        if cd is None or cd is _state["dtype"]:
+            return backward(ctx, *grads)
+        with compute_as(cd):
+            return backward(ctx, *grads)
+    wrapped.__name__ = backward.__name__
+    wrapped.__doc__ = backward.__doc__
+    return wrapped
+
+
 _tls = threading.local()        # per Python thread: second_order flag
 
 
@@ -89,7 +123,7 @@ def cast(t):
         key = id(t)
         hit = _cast_cache.get(key)
         ver = (t._version, _param_epoch.get(key, 0))
-        if hit is not None and hit[0]() is t and hit[1] == ver and hit[2] == t.data_ptr():
+        if hit is not None and hit[0]() is t and hit[1] == ver and hit[2] == t.data_ptr() and hit[3].dtype == cd:
             return hit[3]
         c = t.detach().to(cd)
         _cast_cache[key] = (weakref.ref(t), ver, t.data_ptr(), c)
@@ -260,6 +294,7 @@ class _Matmul(Function):
 
     @staticmethod
     def forward(ctx, a, b, tb, out_dtype, heads_last=False):
+        ctx.cd = _state["dtype"]
         ctx.save_for_backward(a, b)
         ctx.tb = tb
         if (not tb and not heads_last and a.dim() == 2 and b.dim() == 2 and isinstance(b, torch.nn.Parameter)
@@ -272,6 +307,14 @@ class _Matmul(Function):
                 return gemm(cast(a), wt, True, out_dtype or _state["dtype"])
         ac, bc = cast(a), cast(b)
         out = None
+        if ac.dtype == torch.float32 and out_dtype == torch.bfloat16:
+            # an fp32 island (compute_as) handing a gradient back to a bf16 producer: fp32 product, one rounding
+            return _Matmul._product(ac, bc, tb, torch.float32, heads_last).to(torch.bfloat16)
+        return _Matmul._product(ac, bc, tb, out_dtype, heads_last)
+
+    @staticmethod
+    def _product(ac, bc, tb, out_dtype, heads_last):
+        out = None
         if heads_last:          # [B,H,M,N] result stored as [B,M,H,N] (the "unshape" layout, mha.py:126-129)
             B, H, M = ac.shape[0], ac.shape[1], ac.shape[2]
             N = bc.shape[-2] if tb else bc.shape[-1]
@@ -279,6 +322,7 @@ class _Matmul(Function):
         return gemm(ac, bc, tb, out_dtype or _state["dtype"], out=out)
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, dc):
         a, b = ctx.saved_tensors
         da = db = None
@@ -301,6 +345,7 @@ class _Gate(Function):
 
     @staticmethod
     def forward(ctx, x, gate):
+        ctx.cd = _state["dtype"]
         x = cast(x).contiguous()
         gate = cast(gate).contiguous()
         ctx.save_for_backward(gate)
@@ -310,6 +355,7 @@ class _Gate(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         gate, = ctx.saved_tensors
         return _Gate.apply(g, gate), None
@@ -320,6 +366,7 @@ class _Colsum(Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.cd = _state["dtype"]
         x = cast(x)
         x2 = x.reshape(-1, x.shape[-1])
         if x2.stride(-1) != 1:
@@ -332,6 +379,7 @@ class _Colsum(Function):
         return out
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         return g.to(ctx.dtype).expand(ctx.shape)
 
@@ -342,6 +390,7 @@ class _Linear(Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu, residual):
+        ctx.cd = _state["dtype"]
         xc = cast(x)
         if xc.stride(-1) != 1:
             xc = xc.contiguous()
@@ -362,6 +411,7 @@ class _Linear(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dz = _Gate.apply(dy, y) if ctx.relu else dy
@@ -384,6 +434,7 @@ def linear(x, weight, bias=None, relu=False, residual=None):
 class _LayerNorm(Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
+        ctx.cd = _state["dtype"]
         xc = cast(x).contiguous()
         L.require_cuda(xc, gamma, beta)
         d = xc.shape[-1]
@@ -399,6 +450,7 @@ class _LayerNorm(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         dx, dg, db = _LayerNormBwd.apply(dy, x, gamma, mean, rstd)
@@ -408,6 +460,7 @@ class _LayerNorm(Function):
 class _LayerNormBwd(Function):
     @staticmethod
     def forward(ctx, dy, x, gamma, mean, rstd):
+        ctx.cd = _state["dtype"]
         xc, dyc = cast(x).contiguous(), cast(dy).contiguous()
         d = xc.shape[-1]
         rows = xc.numel() // d
@@ -428,6 +481,7 @@ class _LayerNormBwd(Function):
 
     @staticmethod
     @once_differentiable
+    @_in_forward_dtype
     def backward(ctx, ggx, ggg, ggb):
         dy, x, gamma, mean, rstd = ctx.saved_tensors
         xc, dyc = cast(x).contiguous(), cast(dy).contiguous()
@@ -475,6 +529,7 @@ class _Softmax(Function):
 
     @staticmethod
     def forward(ctx, x, mask, scale, log_mode, out_dtype):
+        ctx.cd = _state["dtype"]
         xc = cast(x).contiguous()
         L.require_cuda(xc)
         n = xc.shape[-1]
@@ -489,6 +544,7 @@ class _Softmax(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, dy):
         y, = ctx.saved_tensors
         dx = _SoftmaxBwd.apply(y, dy, ctx.scale, ctx.log_mode, ctx.in_dtype)
@@ -503,6 +559,7 @@ class _Softmax(Function):
 class _SoftmaxBwd(Function):
     @staticmethod
     def forward(ctx, y, dy, scale, log_mode, dx_dtype):
+        ctx.cd = _state["dtype"]
         yc, dyc = y.contiguous(), dy.contiguous()
         n = yc.shape[-1]
         rows = yc.numel() // n
@@ -514,6 +571,7 @@ class _SoftmaxBwd(Function):
         return dx
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         y, dy = ctx.saved_tensors
         if ctx.log_mode:
@@ -546,6 +604,7 @@ class _MaskScale(Function):
 
     @staticmethod
     def forward(ctx, x, keep, scale):
+        ctx.cd = _state["dtype"]
         xc = cast(x).contiguous()
         y = torch.empty_like(xc)
         L.check(L.load().mssr_mask_scale(xc.data_ptr(), keep.data_ptr(), None, y.data_ptr(), xc.numel(), scale,
@@ -555,6 +614,7 @@ class _MaskScale(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         keep, = ctx.saved_tensors
         return _MaskScale.apply(g, keep, ctx.scale).to(ctx.dtype), None, None
@@ -565,6 +625,7 @@ class _Dropout(Function):
 
     @staticmethod
     def forward(ctx, x, p, residual):
+        ctx.cd = _state["dtype"]
         xc = cast(x).contiguous()
         L.require_cuda(xc)
         rc = None if residual is None else cast(residual).contiguous()
@@ -578,6 +639,7 @@ class _Dropout(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         keep, = ctx.saved_tensors
         dx = _MaskScale.apply(g, keep, ctx.scale)
@@ -600,6 +662,7 @@ class _Axpby(Function):
 
     @staticmethod
     def forward(ctx, x, z, a, b):
+        ctx.cd = _state["dtype"]
         xc = cast(x).contiguous()
         L.require_cuda(xc)
         zc = None if z is None else cast(z).contiguous()
@@ -611,6 +674,7 @@ class _Axpby(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         gx = g if ctx.a == 1.0 else _Axpby.apply(g, None, ctx.a, 0.0)
         gz = None
@@ -638,6 +702,7 @@ class _ScaleAddPe(Function):
 
     @staticmethod
     def forward(ctx, x, pe, step, s):
+        ctx.cd = _state["dtype"]
         xc = cast(x).contiguous()            # [len, B, d]
         L.require_cuda(xc, pe)
         ln, B, d = xc.shape
@@ -649,6 +714,7 @@ class _ScaleAddPe(Function):
         return y
 
     @staticmethod
+    @_in_forward_dtype
     def backward(ctx, g):
         gx = _Axpby.apply(g, None, ctx.s, 0.0)
         return (gx if gx.dtype == ctx.dtype else gx.to(ctx.dtype)), None, None, None
@@ -663,6 +729,7 @@ class _EmbedPe(Function):
 
     @staticmethod
     def forward(ctx, ids, weight, pe, step, s, pad_idx):
+        ctx.cd = _state["dtype"]
         L.require_cuda(ids, weight, pe)
         ln, B = ids.shape
         V, d = weight.shape
@@ -678,6 +745,7 @@ class _EmbedPe(Function):
 
     @staticmethod
     @once_differentiable
+    @_in_forward_dtype
     def backward(ctx, g):
         idc, = ctx.saved_tensors
         V, d = ctx.shape
@@ -744,6 +812,7 @@ class _FusedAttention(Function):
 
     @staticmethod
     def forward(ctx, q, k, v, mask, p_drop, want_probs):
+        ctx.cd = _state["dtype"]
         qc, kc, vc = _as_head_view(q), _as_head_view(k), _as_head_view(v)
         L.require_cuda(qc, kc, vc)
         B, H, Lq, dh = qc.shape
@@ -770,6 +839,7 @@ class _FusedAttention(Function):
 
     @staticmethod
     @once_differentiable
+    @_in_forward_dtype
     def backward(ctx, dctx, _dprobs):
         qc, kc, vc, m = ctx.saved_tensors
         B, H, Lq, dh = qc.shape

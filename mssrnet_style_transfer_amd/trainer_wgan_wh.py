@@ -148,6 +148,13 @@ class Trainer:
         return self._gain(self.text_discriminator(x, lengths), self.cfg.gain_mode_t)
 
     def _call_style_discriminator(self, x, lengths):
+        # cfg.style_critic_fp32: the style critic (an MLP on [B, L, 256] representations, < 1 % of the step's
+        # arithmetic) always computes in fp32, forward, backward and the gradient penalty's double backward
+        # (ops.compute_as: every op's backward follows its forward's dtype).  In bf16 its parameter gradients
+        # missed the 2e-2 bar against the reference (tests/test_gpu_parity_readme.py) by 2-3x.
+        if self.cfg.style_critic_fp32 and ops.compute_dtype() != torch.float32:
+            with ops.compute_as(torch.float32):
+                return self._gain(self.style_discriminator(x, lengths), self.cfg.gain_mode_s)
         return self._gain(self.style_discriminator(x, lengths), self.cfg.gain_mode_s)
 
     def unpack_batch(self, batch):

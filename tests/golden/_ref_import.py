@@ -14,7 +14,9 @@ import warnings
 REF = "/root/reference"
 
 
-def import_reference():
+def import_reference(before_imports=None):
+    """``before_imports``: called after the ``onmt`` namespace exists and before any reference module is
+    imported (make_alias_fixture.py registers the drop-in L1 modules there)."""
     sys.dont_write_bytecode = True
     warnings.filterwarnings("ignore", category=FutureWarning)
     if "onmt" in sys.modules and getattr(sys.modules["onmt"], "_is_ref", False):
@@ -25,6 +27,8 @@ def import_reference():
     onmt.__path__ = [REF + "/onmt"]
     onmt._is_ref = True
     sys.modules["onmt"] = onmt
+    if before_imports is not None:
+        before_imports()
 
     def stub(name, **attrs):
         m = types.ModuleType(name)

@@ -679,16 +679,207 @@ def time_reference():
     print("wrote", path)
 
 
+
+# ------------------------------------------------------ README widths / config-5 shape / peaked greedy
+def mixed_grads(m, full_below=4096, n_samples=256):
+    """Gradients of a network as fixtures that stay small at README widths: tensors up to ``full_below`` elements
+    whole, larger ones as {sum, abssum, 256 evenly spaced samples}; plus the network's largest |gradient| (the
+    scale of helpers.assert_grads)."""
+    out, top = {}, 0.0
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            out[k] = None
+            continue
+        g = p.grad.detach()
+        top = max(top, float(g.abs().max()))
+        if g.numel() <= full_below:
+            out[k] = g.clone()
+        else:
+            t = g.double().reshape(-1)
+            idx = torch.linspace(0, t.numel() - 1, n_samples).long()
+            out[k] = dict(sum=t.sum().item(), abssum=t.abs().sum().item(), samples=t[idx].float().clone(),
+                          numel=t.numel())
+    out["_max"] = top
+    return out
+
+
+def seeded_nets(cfg, seed):
+    """Reference networks whose weights both sides can rebuild from ``seed`` (tests/golden/_seeded.py): nothing of
+    the 90 MB of README-width parameters is stored."""
+    nets = build_ref_nets(cfg, seed)
+    for i, (k, m) in enumerate(sorted(nets.items())):
+        m.load_state_dict(seeded_state(sd(m), seed + 17 * i))
+    return nets
+
+
+def run_phases(cfg, batch, seed, phases, full_below=4096):
+    rbatch = SimpleNamespace(src=(batch.src, batch.src_lengths), tgt=batch.tgt, batch_size=batch.batch_size)
+    out = {}
+    specs = {"discriminator": ("train_discriminator", "disc_logger", ("text_discriminator", "style_discriminator")),
+             "generator": ("train_generator", "main_logger", ("model", "style_generator")),
+             "reconstruct": ("train_reconstruct", "reconstruct_logger", ("model", "style_generator"))}
+    for name in phases:
+        fn, lgname, trained = specs[name]
+        nets = seeded_nets(cfg, seed)
+        tr = ref_trainer(cfg, nets)
+        s = 2000 + len(name)
+        torch.manual_seed(s)
+        random.seed(s)
+        getattr(tr, fn)(rbatch)
+        out[name] = dict(seed=s, scalars=logger_vals(getattr(tr, lgname)),
+                         grads={k: mixed_grads(nets[k], full_below) for k in trained})
+        print(name, out[name]["scalars"], flush=True)
+    return out
+
+
+def readme_cfg():
+    """README widths (d512 = 8 x 64, ff1024, V = 9606, critics / teacher / style generator 8 x 32 and 8 x 64) with
+    2 main layers and dropout 0: the shapes the benchmark's kernels actually take (split-K vocabulary products,
+    32x32 skinny tiles, dh 64 attention, LN-folded generator)."""
+    return MSSRConfig(layers=2, dropout=0.0, attention_dropout=0.0)
+
+
+def gen_readme():
+    cfg = readme_cfg()
+    batch = make_batch(8, 16, cfg.vocab_size, seed=31)
+    out = dict(net_seed=400, batch_seed=31, batch_size=8, max_words=16,
+               cfg=dict(layers=2, dropout=0.0, attention_dropout=0.0))
+    out.update(run_phases(cfg, batch, 400, ("discriminator", "generator", "reconstruct")))
+    # teacher step at the TRUE teacher config (3 layers, 8 x 32, ff 1024, V = 9606): SURVEY 8c item 3
+    nets = seeded_nets(cfg, 400)
+    tr = ref_trainer(cfg, nets)
+    rbatch = SimpleNamespace(src=(batch.src, batch.src_lengths), tgt=batch.tgt, batch_size=batch.batch_size)
+    labels, _, real_src, real_len, vocab_target = tr.unpack_batch(rbatch)
+    teacher = nets["teacher"]
+    teacher.train()
+    zero(teacher)
+    lf = nn.NLLLoss()
+    lg1 = teacher(real_src, real_len)
+    loss = lf(torch.log_softmax(lg1, -1), labels)
+    loss = loss + lf(torch.log_softmax(teacher(vocab_target, real_len + 1), -1), labels)
+    loss = loss + lf(torch.log_softmax(teacher(vocab_target, torch.ones_like(real_len) * vocab_target.size(0)), -1),
+                     labels)
+    loss.backward()
+    out["teacher_step"] = dict(loss=loss.detach(), logits=lg1.detach(), g=mixed_grads(teacher))
+    out["param_counts"] = {k: sum(p.numel() for p in m.parameters()) for k, m in build_ref_nets(MSSRConfig(), 1).items()}
+    print("param counts at the full README config", out["param_counts"])
+    return out
+
+
+def long_cfg():
+    return MSSRConfig.small()
+
+
+def gen_long():
+    """BASELINE config 5's shape class: 64..128-word sentences (T = 130 teacher-forced rows, 128 / 140 decode
+    steps, attention over more than 64 keys) at the small widths, so the reference finishes in seconds."""
+    cfg = long_cfg()
+    batch = make_batch(4, 128, cfg.vocab_size, seed=41, min_words=64)
+    out = dict(net_seed=500, batch_seed=41, batch_size=4, max_words=128, min_words=64)
+    out.update(run_phases(cfg, batch, 500, ("discriminator", "generator", "reconstruct"), full_below=1 << 20))
+    return out
+
+
+def decisive_generator(model, cfg, alpha, perm_seed):
+    """Random weights give near-uniform, near-tied next-token distributions (top-2 margins of a few 1e-3 of the logit
+    scale: coin flips at ANY precision below fp32), unlike a trained model.  Add a trained-like decisive component to
+    the generator: row pi(t) += alpha * E_dec[t] for a fixed random permutation pi, i.e. "after token t comes pi(t)",
+    on top of the random generator rows and with every random layer left at full strength."""
+    g = torch.Generator().manual_seed(perm_seed)
+    perm = torch.randperm(cfg.vocab_size, generator=g)
+    with torch.no_grad():
+        E = model.decoder.embeddings.word_lut.weight
+        model.generator[0].weight[perm] += alpha * E * (E.shape[1] ** 0.5)
+    return perm
+
+
+def greedy_case(alpha, perm_seed=77, steps=20):
+    cfg = readme_cfg()
+    nets = seeded_nets(cfg, 600)
+    model, sgen = nets["model"], nets["style_generator"]
+    decisive_generator(model, cfg, alpha, perm_seed)
+    model.eval()
+    sgen.eval()
+    batch = make_batch(32, 16, cfg.vocab_size, seed=51)
+    src, lens = batch.src[1:], batch.src_lengths - 1
+    desired = 1 - batch.labels
+    ids, margins, scales = [], [], []
+    with torch.no_grad():
+        rep = sgen(desired, src, lens)
+        enc_state, mem, _ = model.encoder(src, lens)
+        mem = model.bond_layer(mem, rep)
+        model.decoder.init_state(src, mem, enc_state)
+        cur = torch.full((1, src.size(1), 1), cfg.bos_idx, dtype=torch.long)
+        for step in range(steps):
+            dec_out, _ = model.decoder(cur, mem, memory_lengths=lens, step=step)
+            logits = model.generator[0](dec_out.squeeze(0))
+            top2 = logits.topk(2, dim=-1)
+            ids.append(top2.indices[:, 0].clone())
+            margins.append((top2.values[:, 0] - top2.values[:, 1]).clone())
+            scales.append(logits.abs().max(-1).values.clone())
+            cur = top2.indices[:, 0].view(1, -1, 1)
+    ids, margins, scales = torch.stack(ids), torch.stack(margins), torch.stack(scales)
+    rel = margins / scales
+    print("greedy_big alpha %.2f: distinct tokens %d, relative top-2 margin median %.3f, min %.4f, below 1%%: %d of %d"
+          % (alpha, ids.unique().numel(), float(rel.median()), float(rel.min()), int((rel < 0.01).sum()), rel.numel()))
+    return dict(alpha=alpha, perm_seed=perm_seed, steps=steps, ids=ids, rel_margins=rel)
+
+
+def gen_greedy_big():
+    """Greedy decode on README widths (2 layers), 32 sentences x 20 steps = 640 tokens: the population the >= 99 %
+    bf16 token-match bar of north_star is checked on (fp32 must match exactly).  Two generators: "decisive" (every
+    top-2 margin above 2 % of the logit scale, as a trained model mostly is) and "mixed" (weaker structure: the random
+    layers decide more, sentences diverge, and a dozen positions are ties below 1 % that no 8-bit-mantissa arithmetic
+    can be asked to reproduce: the test stops counting a sentence at its first such position)."""
+    return dict(net_seed=600, batch_seed=51, batch_size=32, max_words=16,
+                decisive=greedy_case(0.08), mixed=greedy_case(0.06))
+
+
+def gen_pickles():
+    """Whole-module pickles written from the REFERENCE's classes (what onmt/trainer_wgan_wh.py:1093-1100 and
+    trainer_teacher.py:282 save, what translator_wh.py:29-35 / cls_proxy.py:14-22 load): class paths onmt.*; small
+    widths; with an input / output pair per module so a loader can be checked for behaviour, not just for keys."""
+    cfg = MSSRConfig.small()
+    nets = build_ref_nets(cfg, 700)
+    batch = make_batch(5, 7, cfg.vocab_size, seed=61)
+    src, lens = batch.src[1:], batch.src_lengths - 1
+    desired = 1 - batch.labels
+    for m in nets.values():
+        m.eval()
+    with torch.no_grad():
+        rep = nets["style_generator"](desired, src, lens)
+        logits = nets["teacher"](src, lens)
+        tlogits = nets["text_discriminator"](src, lens)
+        slogits = nets["style_discriminator"](rep.transpose(0, 1).contiguous(), lens)
+        enc_state, mem, _ = nets["model"].encoder(src, lens)
+        mem = nets["model"].bond_layer(mem, rep)
+        nets["model"].decoder.init_state(src, mem, enc_state)
+        dec_out, attns = nets["model"].decoder(batch.tgt[:-1], mem, memory_lengths=lens)
+        logp = nets["model"].generator(dec_out)
+    nets["model"].decoder.state = {}
+    path = os.path.join(HERE, "ref_pickles.pt")
+    torch.save({"main_model": nets["model"], "style_generator": nets["style_generator"],
+                "style_discriminator": nets["style_discriminator"], "text_discriminator": nets["text_discriminator"],
+                "teacher": nets["teacher"], "step": 7,
+                "io": dict(src=src, lens=lens, desired=desired, tgt=batch.tgt, rep=rep, teacher_logits=logits,
+                           tdisc_logits=tlogits, sdisc_logits=slogits, dec_out=dec_out, attn_std=attns["std"],
+                           logp=logp)}, path)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     os.makedirs("/tmp/mssr_golden", exist_ok=True)
     if sys.argv[1:] == ["flops"]:
         return gen_flops()
     if sys.argv[1:] == ["reftime"]:
         return time_reference()
+    if sys.argv[1:] == ["pickles"]:
+        return gen_pickles()
     which = sys.argv[1:] or ["ops", "modules", "phases", "greedy"]
     meta = dict(torch=str(torch.__version__), note="generated from /root/reference by tests/golden/make_golden.py")
     for name in which:
-        data = {"ops": gen_ops, "modules": gen_modules, "phases": gen_phases, "greedy": gen_greedy}[name]()
+        data = {"ops": gen_ops, "modules": gen_modules, "phases": gen_phases, "greedy": gen_greedy, "readme": gen_readme,
+                "long": gen_long, "greedy_big": gen_greedy_big}[name]()
         data["_meta"] = meta
         path = os.path.join(HERE, name + ".pt")
         torch.save(data, path)
