@@ -103,6 +103,19 @@ typedef struct {
     float ln_eps;
 } mssr_gemm_desc;
 int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
+/* mssr_gemm for callers that CANNOT ALLOCATE -- code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc.  No counterpart in the reference (its ops allocate freely through torch).  Same descriptor and
+ * results as mssr_gemm, bit for bit; desc->workspace is ignored: the split-K slabs of the K-split kernel (k > 2048)
+ * live in a file-scope device array of MSSR_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until
+ * the process ends (looked up once per device with hipGetSymbolAddress; nothing is ever allocated or freed).
+ * A split-K problem whose slabs ceil(k/1024) * m * n * 4 bytes exceed that size is rejected with MSSR_ERR_ARG and a
+ * message (mssr_gemm with a workspace takes it); problems that need no slabs (k <= 2048, or the general kernel's
+ * shapes) run as in mssr_gemm.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
+ * (different streams, different threads) race on it -- serialise them or use mssr_gemm with per-stream workspaces.
+ * Nothing in the array has to start at zero: every slab element is written before it is read. */
+#define MSSR_NOALLOC_SCRATCH_BYTES (16u << 20)
+int mssr_gemm_noalloc(const mssr_gemm_desc* desc, void* stream);
+int64_t mssr_gemm_noalloc_scratch_bytes(void);
 /* Block tile edge (64 or 32) mssr_gemm picks for an m x n x batch problem; lets a profiler name the
  * kernel instance (gemm_kernel<.., 64, 64> / <.., 32, 32>) a launch used.  No reference counterpart. */
 int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);

@@ -97,6 +97,8 @@ SIGNATURES = {
     "mssr_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
     "mssr_layernorm_bwd_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
     "mssr_gemm": ([POINTER(GemmDesc), _P], c_int),
+    "mssr_gemm_noalloc": ([POINTER(GemmDesc), _P], c_int),
+    "mssr_gemm_noalloc_scratch_bytes": ([], c_int64),
     "mssr_gemm_tile": ([_L, _L, _L], c_int),
     "mssr_gemm_is_skinny": ([POINTER(GemmDesc)], c_int),
     "mssr_softmax_fwd": ([_P, _P, _P, _L, _I, _L, _L, _L, _L, _L, _L, _F, _I, _I, _I, _P], c_int),

@@ -7,6 +7,7 @@
 // Operands may be k-contiguous ("NT" weights, activations) or row-contiguous (transposed
 // views: dW = dY^T X, P V, ...): the loader picks the coalesced direction per operand.
 #include "gemm_common.hpp"
+#include <mutex>
 #include <stdlib.h>
 
 namespace mssr {
@@ -249,26 +250,26 @@ extern "C" int mssr_gemm_is_skinny(const mssr_gemm_desc* d) {
     return gemm_skinny_eligible(a, d->in_dtype, d->batch_outer * d->batch_inner) ? 1 : 0;
 }
 
-extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
-    MSSR_REQUIRE(d, "gemm: null descriptor");
-    MSSR_REQUIRE(valid_dtype(d->in_dtype) && valid_dtype(d->out_dtype), "gemm: bad dtype");
-    MSSR_REQUIRE(!(d->in_dtype == MSSR_F32 && d->out_dtype == MSSR_BF16), "gemm: f32 -> bf16 is not supported");
-    MSSR_REQUIRE(d->m >= 0 && d->n >= 0 && d->k >= 0, "gemm: negative size");
-    MSSR_REQUIRE(d->batch_outer >= 1 && d->batch_inner >= 1, "gemm: batch counts must be >= 1");
+static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
+    MSSR_REQUIRE(d, "%s: null descriptor", who);
+    MSSR_REQUIRE(valid_dtype(d->in_dtype) && valid_dtype(d->out_dtype), "%s: bad dtype", who);
+    MSSR_REQUIRE(!(d->in_dtype == MSSR_F32 && d->out_dtype == MSSR_BF16), "%s: f32 -> bf16 is not supported", who);
+    MSSR_REQUIRE(d->m >= 0 && d->n >= 0 && d->k >= 0, "%s: negative size", who);
+    MSSR_REQUIRE(d->batch_outer >= 1 && d->batch_inner >= 1, "%s: batch counts must be >= 1", who);
     const int64_t batch = d->batch_outer * d->batch_inner;
-    MSSR_REQUIRE(batch <= 65535, "gemm: batch %lld exceeds 65535", (long long)batch);
+    MSSR_REQUIRE(batch <= 65535, "%s: batch %lld exceeds 65535", who, (long long)batch);
     if (d->m == 0 || d->n == 0) return MSSR_OK;
-    MSSR_REQUIRE(d->a && d->b && d->c, "gemm: null pointer");
-    MSSR_REQUIRE(d->a_rs == 1 || d->a_cs == 1, "gemm: A needs a unit stride (a_rs=%lld a_cs=%lld)",
+    MSSR_REQUIRE(d->a && d->b && d->c, "%s: null pointer", who);
+    MSSR_REQUIRE(d->a_rs == 1 || d->a_cs == 1, "%s: A needs a unit stride (a_rs=%lld a_cs=%lld)", who,
                  (long long)d->a_rs, (long long)d->a_cs);
-    MSSR_REQUIRE(d->b_rs == 1 || d->b_cs == 1, "gemm: B needs a unit stride (b_rs=%lld b_cs=%lld)",
+    MSSR_REQUIRE(d->b_rs == 1 || d->b_cs == 1, "%s: B needs a unit stride (b_rs=%lld b_cs=%lld)", who,
                  (long long)d->b_rs, (long long)d->b_cs);
-    MSSR_REQUIRE(d->ldc >= d->n, "gemm: ldc < n");
-    MSSR_REQUIRE(!d->residual || d->ldr >= d->n, "gemm: ldr < n");
-    MSSR_REQUIRE(!d->gate || d->ldg >= d->n, "gemm: ldg < n");
-    MSSR_REQUIRE((d->m + 31) / 32 <= 65535, "gemm: m too large");
+    MSSR_REQUIRE(d->ldc >= d->n, "%s: ldc < n", who);
+    MSSR_REQUIRE(!d->residual || d->ldr >= d->n, "%s: ldr < n", who);
+    MSSR_REQUIRE(!d->gate || d->ldg >= d->n, "%s: ldg < n", who);
+    MSSR_REQUIRE((d->m + 31) / 32 <= 65535, "%s: m too large", who);
 
-    MSSR_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "gemm: drop_p=%f out of [0,1)", d->drop_p);
+    MSSR_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "%s: drop_p=%f out of [0,1)", who, d->drop_p);
     GemmArgs a;
     gemm_fill_args(d, a);
     hipStream_t s = (hipStream_t)stream;
@@ -283,8 +284,8 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
         MSSR_LAUNCH_OK("gemm(tn)");
     }
     if (d->ln_colsum) {
-        set_error("gemm: the LayerNorm prologue needs the K-split kernel (bf16, m <= 8192, k <= 2048, k %% 32 == 0, "
-                  "k-contiguous 16-byte aligned operands)");
+        set_error("%s: the LayerNorm prologue needs the K-split kernel (bf16, m <= 8192, k <= 2048, k %% 32 == 0, "
+                  "k-contiguous 16-byte aligned operands)", who);
         return MSSR_ERR_UNSUPPORTED;
     }
     if (d->in_dtype == MSSR_F32) launch<float, float>(a, batch, s);
@@ -292,4 +293,75 @@ extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) {
     else launch<bf16, float>(a, batch, s);
     prof_end(pi, s, 0, d->in_dtype, d->out_dtype, use_tile64(d->m, d->n, batch) ? 64 : 32, batch, d->m, d->n, d->k);
     MSSR_LAUNCH_OK("gemm");
+}
+
+extern "C" int mssr_gemm(const mssr_gemm_desc* d, void* stream) { return gemm_run(d, stream, "gemm"); }
+
+// ------------------------------------------------------------------ the allocation-free variant
+// mssr_gemm for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+// forbid hipMalloc): the split-K slabs of the K-split kernel -- the library's one scratch buffer, a caller-supplied
+// workspace in mssr_gemm -- live in a file-scope device array instead.  Each GPU the library runs on holds its own
+// copy of the array (MSSR_NOALLOC_SCRATCH_BYTES) at its own address until the process ends; the address is looked
+// up once per device with hipGetSymbolAddress and only that pointer is ever handed to kernels (the array's NAME in
+// host code is a host-side stand-in, not a device address).
+static __device__ __align__(256) unsigned char scratch[MSSR_NOALLOC_SCRATCH_BYTES];
+
+namespace {
+constexpr int kMaxDevices = 64;
+struct ScratchSlot {
+    std::mutex mu;
+    void* ptr = nullptr;
+};
+ScratchSlot g_scratch[kMaxDevices];
+}  // namespace
+
+// the calling thread's current device's copy of `scratch`; nullptr + error message on failure
+static void* scratch_of_current_device(const char* who) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+        set_error("%s: cannot identify the current device", who);
+        return nullptr;
+    }
+    ScratchSlot& slot = g_scratch[dev];
+    std::lock_guard<std::mutex> lock(slot.mu);
+    if (!slot.ptr) {
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            set_error("%s: hipGetSymbolAddress(scratch) failed on device %d: %s", who, dev, hipGetErrorString(e));
+            return nullptr;
+        }
+        slot.ptr = p;
+    }
+    return slot.ptr;
+}
+
+extern "C" int64_t mssr_gemm_noalloc_scratch_bytes(void) { return (int64_t)MSSR_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int mssr_gemm_noalloc(const mssr_gemm_desc* d, void* stream) {
+    MSSR_REQUIRE(d, "gemm_noalloc: null descriptor");
+    mssr_gemm_desc local = *d;
+    local.workspace = nullptr;                 // the caller's workspace, if any, is not used
+    local.workspace_bytes = 0;
+    if (valid_dtype(d->in_dtype) && d->m > 0 && d->n > 0 && d->k > 32 * 64) {
+        // would the K-split kernel take this problem if it had its slabs?  (probe with a non-null placeholder that
+        // is never dereferenced: eligibility only tests it against nullptr)
+        GemmArgs probe;
+        gemm_fill_args(&local, probe);
+        probe.partial = reinterpret_cast<float*>(uintptr_t(256));
+        if (!d->no_skinny && !d->ln_colsum &&
+            gemm_skinny_eligible(probe, d->in_dtype, d->batch_outer * d->batch_inner)) {
+            const int64_t need = gemm_skinny_ksplit(d->k) * d->m * d->n * (int64_t)sizeof(float);
+            MSSR_REQUIRE(need <= (int64_t)MSSR_NOALLOC_SCRATCH_BYTES,
+                         "gemm_noalloc: split-K slabs of a %lld x %lld x %lld product need %lld bytes, beyond the "
+                         "%lld-byte static scratch (use mssr_gemm with a workspace)",
+                         (long long)d->m, (long long)d->n, (long long)d->k, (long long)need,
+                         (long long)MSSR_NOALLOC_SCRATCH_BYTES);
+            void* ptr = scratch_of_current_device("gemm_noalloc");
+            if (!ptr) return MSSR_ERR_LAUNCH;
+            local.workspace = ptr;             // every slab element is written before the reduce kernel reads it:
+            local.workspace_bytes = (int64_t)MSSR_NOALLOC_SCRATCH_BYTES;   // nothing has to start at zero
+        }
+    }
+    return gemm_run(&local, stream, "gemm_noalloc");
 }
