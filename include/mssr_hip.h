@@ -185,6 +185,28 @@ int mssr_colsum_batched(const void* x, float* out, int batch, int64_t x_bs, int6
 int mssr_axpby(const void* x, const void* z, void* y, int64_t n, float a, float b, int dtype,
                void* stream);
 
+/* ------------------------------------------------------- gradient norm, clipping, Adam -----
+ * One optimizer step of a whole network: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step()
+ * as built and called by the reference trainer (onmt/trainer_wgan_wh.py:192-211 Adam(lr, betas=(beta1, beta2)),
+ * :623-628 and :973-977 clip then step; onmt/trainer_teacher.py:220,265-267).  `params`, `grads`, `numels`,
+ * `state_offsets` are HOST arrays of n entries; params[i] / grads[i] are DEVICE pointers to contiguous fp32 tensors of
+ * numels[i] elements, 16-byte aligned; grads[i] == NULL: the parameter received no gradient and is skipped, as torch
+ * skips it.  Pointers travel in kernel arguments (96 tensors per launch): nothing is uploaded or allocated. */
+/* floats of scratch mssr_grad_norm needs for n tensors */
+int64_t mssr_grad_norm_scratch_floats(int n_tensors);
+/* out[0] = global L2 norm of all gradients, out[1] = clip coefficient min(1, max_norm / (norm + 1e-6)) (1 when
+ * max_norm <= 0).  Deterministic two-stage reduction (no atomics).  partial: float[mssr_grad_norm_scratch_floats(n)]. */
+int mssr_grad_norm(int n, void* const* grads, const int64_t* numels, float max_norm, float* partial, float* out,
+                   void* stream);
+/* Adam with bias correction, no weight decay, no amsgrad.  steps[i] (host array) = how many updates tensor i has had
+ * INCLUDING this one (torch.optim.Adam counts steps per parameter: one that got no gradient lags).  The moments of tensor i live at
+ * exp_avg + state_offsets[i] / exp_avg_sq + state_offsets[i] (offsets multiples of 4).  norm_coef: the `out` of
+ * mssr_grad_norm (gradients are multiplied by out[1] on the fly) or NULL; write_clipped != 0 also stores the
+ * scaled gradients back, as clip_grad_norm_ does. */
+int mssr_adam_step(int n, void* const* params, void* const* grads, const int64_t* numels,
+                   const int64_t* state_offsets, float* exp_avg, float* exp_avg_sq, const float* norm_coef, float lr,
+                   float beta1, float beta2, float eps, const int32_t* steps, int write_clipped, void* stream);
+
 /* ---------------------------------------------------------------- embeddings + PE ---------
  * Replaces nn.Embedding lookup + PositionalEncoding (onmt/modules/embeddings.py:48-54,282):
  * out[r,:] = W[ids[r],:]*scale + pe[pos(r),:],  pos(r) = step >= 0 ? step : r / batch.

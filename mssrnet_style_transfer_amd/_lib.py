@@ -110,6 +110,9 @@ SIGNATURES = {
     "mssr_colsum": ([_P, _P, _L, _I, _L, _I, _I, _P], c_int),
     "mssr_colsum_batched": ([_P, _P, _I, _L, _L, _I, _L, _I, _P], c_int),
     "mssr_axpby": ([_P, _P, _P, _L, _F, _F, _I, _P], c_int),
+    "mssr_grad_norm_scratch_floats": ([_I], c_int64),
+    "mssr_grad_norm": ([_I, _P, _P, _F, _P, _P, _P], c_int),
+    "mssr_adam_step": ([_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _I, _P], c_int),
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
     "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),

@@ -91,6 +91,12 @@ def params_changed(*modules):
             _param_epoch[id(p)] = _param_epoch.get(id(p), 0) + 1
 
 
+def params_changed_list(params):
+    """params_changed for an explicit list of parameters (the in-tree optimizer calls it after every step)."""
+    for p in params:
+        _param_epoch[id(p)] = _param_epoch.get(id(p), 0) + 1
+
+
 def param_epoch(p):
     return _param_epoch.get(id(p), 0)
 

@@ -38,6 +38,7 @@ class GradSync:
         self._pending = []      # (bucket, work handle)
         self._hooks = []
         self._stream = None
+        self._in_hook = False   # True while a gradient hook (autograd thread) runs: nothing there may block the host
 
     # ---------------------------------------------------------------- bucket plan
     def _plan(self, module):
@@ -85,8 +86,12 @@ class GradSync:
                         return
                     b["ready"] += 1
                     if b["ready"] == len(b["params"]) and not b["launched"]:
-                        self._fill(b)
-                        self._launch(b)
+                        self._in_hook = True
+                        try:
+                            self._fill(b)
+                            self._launch(b)
+                        finally:
+                            self._in_hook = False
                 self._hooks.append(p.register_post_accumulate_grad_hook(hook))
         return plan
 
@@ -113,12 +118,19 @@ class GradSync:
             return
         flat = b["flat"]
         if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # INVARIANT: nothing reachable from a gradient hook may block the host.  This branch does (a device ->
+            # host copy waits for every kernel the host has queued, then a blocking collective): it is reached from
+            # __call__ only, after the phase's last backward has returned (arm() refuses gloo-on-device: _overlap_ok).
+            assert not self._in_hook, "blocking gloo reduction reached from a gradient hook"
             host = flat.cpu()                        # blocking copy: the bucket is final
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
             flat.copy_(host)
             b["launched"] = True
             self._pending.append((b, None))
             return
+        # RCCL (and gloo on host tensors): pure enqueues, safe from a hook -- an event record + stream wait, then an
+        # async collective on the side stream; the handle is waited for in __call__ only (for RCCL that wait is
+        # itself a stream-side event wait, not a host block)
         side = self._side_stream(flat.device)
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(flat.device))
@@ -150,6 +162,7 @@ class GradSync:
     def __call__(self, modules):
         if not self.active:
             return
+        assert not self._in_hook, "GradSync.__call__ (the only place that waits) entered from a gradient hook"
         for m in modules:
             for b in self._plan(m):
                 b["armed"] = False

@@ -14,10 +14,10 @@ from collections.abc import Mapping
 
 import torch
 import torch.nn.functional as F
-from torch.nn.utils import clip_grad_norm_
 
 from . import ops
 from .decode_engine import soft_decode
+from .optim import Adam
 from .train_and_translate import dec_output_length, generator_probs
 from .utils.misc import sequence_mask
 
@@ -122,10 +122,8 @@ class Trainer:
         self.classifier = nets["teacher"]
         self.classifier.eval()
         self.grad_sync = grad_sync
-        on_gpu = next(self.model.parameters()).is_cuda
-        # torch's multi-tensor fused Adam: one kernel per dtype group instead of ~10 foreach passes
-        adam = lambda m: torch.optim.Adam(m.parameters(), lr=cfg.learning_rate,  # noqa: E731
-                                          betas=(cfg.adam_beta1, cfg.adam_beta2), fused=on_gpu)
+        # in-tree multi-tensor Adam (optim.py / csrc/optim.hip): norm + clip + update of a whole network in ~11 launches
+        adam = lambda m: Adam(m, lr=cfg.learning_rate, betas=(cfg.adam_beta1, cfg.adam_beta2))  # noqa: E731
         self.style_generator_optim = adam(self.style_generator)
         self.style_discriminator_optim = adam(self.style_discriminator)
         self.text_discriminator_optim = adam(self.text_discriminator)
@@ -225,12 +223,10 @@ class Trainer:
     def _finish(self, modules, optims, clip=True):
         if self.grad_sync is not None:
             self.grad_sync(modules)
-        if clip and self.cfg.max_grad_norm > 0:
-            for m in modules:
-                clip_grad_norm_(m.parameters(), self.cfg.max_grad_norm)
+        # clip_grad_norm_(net, max_grad_norm) per network, then its Adam step (trainer_wgan_wh.py:623-628,973-977);
+        # the step itself tells the weight caches about the update
         for o in optims:
-            o.step()
-        ops.params_changed(*modules)        # fused optimizers do not bump Parameter._version
+            o.step(self.cfg.max_grad_norm if clip else 0.0)
 
     # ------------------------------------------------------------------ phases
     def train_discriminator(self, batch):

@@ -608,3 +608,38 @@ def test_gemm_tn_weight_gradient_kernel(ops, M, N, K, batch):
         dys, xs = dy[0][:, 3:M - 2], x[0][:, 1:N - 4]
         o = ops.gemm(dys.t(), xs, False, torch.float32)
         assert_close(o, ref[0][3:M - 2, 1:N - 4], 2e-5 * math.sqrt(K), "tn sliced")
+
+
+def test_adam_and_global_norm_clip_match_torch():
+    """csrc/optim.hip against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (what onmt/trainer_wgan_wh.py:192-211,
+    623-628 runs): odd sizes, a parameter without gradient, clipping active and inactive, five steps."""
+    from mssrnet_style_transfer_amd.optim import Adam
+    torch.manual_seed(3)
+    shapes = [(129,), (1, 129), (512, 512), (3,), (9606, 64), (7, 5), (1030,)]
+    mine = [torch.nn.Parameter(torch.randn(s, device="cuda")) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in mine]
+    opt = Adam(mine, lr=4e-3, betas=(0.5, 0.9))
+    topt = torch.optim.Adam(ref, lr=4e-3, betas=(0.5, 0.9))
+    for step in range(5):
+        max_norm = (0.0, 1e9, 5.0, 0.5, 100.0)[step]
+        scale = (1.0, 1.0, 3.0, 0.01, 1.0)[step]
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            if i == 3 and step % 2 == 0:
+                a.grad = b.grad = None              # a parameter that received no gradient this step
+                continue
+            g = torch.randn_like(a) * scale
+            a.grad, b.grad = g.clone(), g.clone()
+        if max_norm > 0:
+            want_norm = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        opt.step(max_norm)
+        topt.step()
+        if max_norm > 0:
+            assert abs(float(opt.last_norm[0]) - float(want_norm)) <= 1e-5 * float(want_norm)
+        for i, (a, b) in enumerate(zip(mine, ref)):
+            assert_close(a, b, 1e-6, "step %d param %d" % (step, i))
+            if a.grad is not None and max_norm > 0:
+                assert_close(a.grad, b.grad, 1e-6, "step %d clipped grad %d" % (step, i))
+    # determinism of the norm: same gradients, same bits
+    n1 = opt.grad_norm(1.0).clone()
+    n2 = opt.grad_norm(1.0).clone()
+    assert torch.equal(n1, n2)
