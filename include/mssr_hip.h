@@ -101,6 +101,9 @@ typedef struct {
     float* ln_mean;
     float* ln_rstd;
     float ln_eps;
+    /* rows below drop_row0 are exempt from the epilogue dropout (kept, not rescaled): eval-mode rows that share a
+     * launch with training-mode rows (mssr_decode_plan.eval_rows).  0 = every row is dropped as drop_p says. */
+    int64_t drop_row0;
 } mssr_gemm_desc;
 int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
 /* mssr_gemm for callers that CANNOT ALLOCATE -- code under HIP graph capture, tight serving loops, harnesses that
@@ -395,6 +398,14 @@ typedef struct {
      * finished ones on (instead of compacting the batch as the reference does) leaves the others unchanged. */
     int32_t* ids;                 /* [T][B] or NULL */
     int greedy;
+    /* Two decodes of the same weights in ONE sweep (no reference counterpart: the reference runs them one after the
+     * other, onmt/trainer_wgan_wh.py:530-535 in eval mode for the critics' fake text and :917-920 in train mode for the
+     * generator step; a sweep costs the same ~100 dependent launches per step whether it carries 80 rows or 240):
+     * sentences [0, eval_rows) run WITHOUT dropout whatever `training` says, and the backward sweep covers sentences
+     * [bwd_row0, B) only (the others carry no gradient).  Both 0 = the plain behaviour.  Need n_chunks = 1 and
+     * eval_rows <= bwd_row0. */
+    int eval_rows;
+    int bwd_row0;
 } mssr_decode_plan;
 /* One decode step: embeds in_all[step], runs the layers with the cache rows 0..step, writes
  * probs[step] and in_all[step+1]. */

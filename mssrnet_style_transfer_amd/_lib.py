@@ -29,7 +29,8 @@ class GemmDesc(Structure):
                 ("in_dtype", c_int), ("out_dtype", c_int),
                 ("drop_p", c_float), ("drop_seed", c_uint64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("no_skinny", c_int),
-                ("ln_colsum", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_eps", c_float)]
+                ("ln_colsum", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_eps", c_float),
+                ("drop_row0", c_int64)]
 
 
 class DecLayer(Structure):
@@ -70,7 +71,7 @@ class DecodePlan(Structure):
                 + [("gemm_ws_bytes", c_int64)]
                 + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dctx",
                                            "ds_self", "ds_ctx", "d_e", "dnf", "ids")]
-                + [("greedy", c_int)])
+                + [("greedy", c_int), ("eval_rows", c_int), ("bwd_row0", c_int)])
 
 
 class AttnDesc(Structure):

@@ -68,6 +68,9 @@ class MSSRConfig:
     # not a reference flag: batch the independent style-generator / encoder / decode calls of the generator
     # phase (same weights, same source) into single calls; results equal up to summation order
     batch_generator_phase: bool = True
+    # not a reference flag: Trainer.train_wgan_step decodes the critics' fake text and the generator phase's texts in
+    # one sweep (False: the two phases run back to back exactly as train_discriminator + train_generator)
+    share_decode_sweep: bool = True
     # not a reference flag: the style critic computes in fp32 even when the compute dtype is bf16
     style_critic_fp32: bool = True
 

@@ -100,4 +100,4 @@ extern "C" int mssr_prof_get(int i, mssr_prof_record* out) {
 }
 
 extern "C" const char* mssr_last_error(void) { return mssr::g_err; }
-extern "C" int mssr_abi_version(void) { return 1; }
+extern "C" int mssr_abi_version(void) { return 2; }

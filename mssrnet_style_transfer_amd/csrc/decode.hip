@@ -30,13 +30,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_step_fwd_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
-    int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0) {
     __shared__ float sc[4][AT_MAXK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bh_raw = blockIdx.x * 4 + wave;
     const bool active = bh_raw < B * H;
     const int bh = active ? bh_raw : B * H - 1;     // idle waves shadow the last slice and store nothing
     const int b = bh / H, h = bh % H;
+    const float p_drop = b >= drop_b0 ? p_drop_all : 0.f;     // eval-mode sentences of a mixed sweep: no dropout
     const T* qp = q + (int64_t)b * q_bs + h * dh;
     const T* kp = k + (int64_t)b * kv_bs + h * dh;
     const T* vp = v + (int64_t)b * kv_bs + h * dh;
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
     T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
-    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
+    int bh_off) {
     __shared__ float s_p[4][AT_MAXK];      // p, then ds
     __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p); then the gathered ds coefficients of later steps
     __shared__ float s_pd[4][AT_MAXK];     // dropped p; then the gathered pd coefficients of later steps
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     for (int t = lane; t < Lk; t += 64) {
         const float p = s[t] * inv;
         float m = 1.0f;
-        if (p_drop > 0.f) m = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? keep_scale : 0.f;
+        if (p_drop > 0.f) m = keep16(seed, (uint64_t)(bh + bh_off) * AT_MAXK + t, thr) ? keep_scale : 0.f;
         const T* vr = vp + (int64_t)t * kv_ts;
         float a = 0.f;
         for (int j = 0; j < dh; j += 4) {
@@ -338,7 +340,7 @@ template <typename T, int LS, int AT_NL>
 __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
-    int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0) {
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -348,6 +350,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     const bool active = bh_raw < B * H;
     const int bh = active ? bh_raw : B * H - 1;
     const int b = bh / H, h = bh % H;
+    const float p_drop = b >= drop_b0 ? p_drop_all : 0.f;     // eval-mode sentences of a mixed sweep: no dropout
     constexpr int LPR = 1 << LS, RPL = 64 >> LS, RC = AT_NL * RPL;
     const int c = lane & (LPR - 1), r = lane >> LS;
     const T* qp = q + (int64_t)b * q_bs + h * dh + c * E;
@@ -432,7 +435,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
     T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
-    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed) {
+    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
+    int bh_off) {
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -518,7 +522,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     for (int t = lane; t < Lk; t += 64) {
         const float p = s[t] * inv;
         float m = 1.0f;
-        if (p_drop > 0.f) m = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? keep_scale : 0.f;
+        if (p_drop > 0.f) m = keep16(seed, (uint64_t)(bh + bh_off) * AT_MAXK + t, thr) ? keep_scale : 0.f;
         const float dp = dpv[t] * m;
         s[t] = p;
         dpv[t] = dp;
@@ -612,7 +616,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
 template <typename T>
 __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict__ e, const float* __restrict__ pe,
                                                              T* __restrict__ out, int rows, int d, int step, float s,
-                                                             float p, uint64_t seed) {
+                                                             float p, uint64_t seed, int drop_row0) {
     const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t thr = drop_thr16(p);
     const int64_t n = (int64_t)rows * d;
@@ -622,14 +626,15 @@ __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict
         V4<T>::load(e + i, v);
         V4<float>::load(pe + (int64_t)step * d + c, pp);
         uint32_t kp[2] = {3u, 3u};          // i is a multiple of 4: two whole decision pairs
-        if (p > 0.f) {
+        const bool drop = p > 0.f && (int)(i / d) >= drop_row0;
+        if (drop) {
             kp[0] = keep16_pair(seed, (uint64_t)i >> 1, thr);
             kp[1] = keep16_pair(seed, ((uint64_t)i >> 1) + 1, thr);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float t = v[j] * s + pp[j];
-            o[j] = (p > 0.f) ? (((kp[j >> 1] >> (j & 1)) & 1u) ? t * sc : 0.f) : t;
+            o[j] = drop ? (((kp[j >> 1] >> (j & 1)) & 1u) ? t * sc : 0.f) : t;
         }
         V4<T>::store(out + i, o);
     }
@@ -699,6 +704,8 @@ __global__ __launch_bounds__(256) void vocab_softmax_kernel(const T* __restrict_
 struct Ctx : GemmCtx {
     const mssr_decode_plan* p;
     int b0, Bc, chunk;
+    int eval_rows;      // forward: rows of this chunk below it skip dropout (mixed eval / train sweep)
+    int hash_row_off;   // backward over a row slice of an unchunked forward: offset of the slice in the forward's rows
 };
 
 static inline uint64_t site_seed(const Ctx& c, int step, int layer, int site) {
@@ -739,7 +746,7 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
 #define MSSR_FWD_TILED_N(LS, NL)                                                                                    \
     attn_step_fwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh, \
-        Lk, 1.0f / sqrtf((float)dh), p_drop, seed)
+        Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows)
 #define MSSR_FWD_TILED(LS)                            \
     do {                                              \
         if (Lk <= 4 * (64 >> LS)) MSSR_FWD_TILED_N(LS, 4); \
@@ -756,7 +763,7 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
 #undef MSSR_FWD_TILED_N
     attn_step_fwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh,
-        Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
+        Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows);
 }
 
 template <typename T>
@@ -774,7 +781,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     attn_step_bwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,    \
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,  \
-        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed)
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads)
 #define MSSR_BWD_TILED(LS)                                                              \
     do {                                                                                \
         const int need = gather && p->T - step > Lk ? p->T - step : Lk;                 \
@@ -793,7 +800,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,
-        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed);
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads);
 }
 
 #define DT_CALL(c, fn, ...)                                   \
@@ -831,6 +838,10 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
     }
     MSSR_REQUIRE(p->n_chunks >= 1 && p->n_chunks <= MAX_CHUNKS, "%s: n_chunks must be in [1, %d]", who, MAX_CHUNKS);
     MSSR_REQUIRE(p->p_drop >= 0.f && p->p_drop < 1.f && p->p_attn >= 0.f && p->p_attn < 1.f, "%s: bad dropout", who);
+    MSSR_REQUIRE(p->eval_rows >= 0 && p->eval_rows <= p->B && p->bwd_row0 >= 0 && p->bwd_row0 < p->B,
+                 "%s: eval_rows / bwd_row0 outside the batch", who);
+    MSSR_REQUIRE((p->eval_rows == 0 && p->bwd_row0 == 0) || (p->n_chunks == 1 && p->eval_rows <= p->bwd_row0),
+                 "%s: a mixed eval / train sweep needs n_chunks = 1 and eval_rows <= bwd_row0", who);
     return MSSR_OK;
 }
 
@@ -898,10 +909,10 @@ static int step_fwd(const Ctx& c, int step) {
         const unsigned g = (unsigned)((Rd / 4 + 255) / 256);
         if (c.dt == MSSR_F32)
             embed_epilogue_kernel<float><<<g, 256, 0, c.s>>>((const float*)G.tmp(), p->pe, (float*)G.X(0), R, d, step,
-                                                             sqrtf((float)d), pd, site_seed(c, step, -1, 0));
+                                                             sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows);
         else
             embed_epilogue_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)G.tmp(), p->pe, (bf16*)G.X(0), R, d, step,
-                                                            sqrtf((float)d), pd, site_seed(c, step, -1, 0));
+                                                            sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows);
     }
     for (int l = 0; l < NL; ++l) {
         const mssr_dec_layer& L = p->layers[l];
@@ -927,7 +938,7 @@ static int step_fwd(const Ctx& c, int step) {
         DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
                 (int64_t)B * 3 * d, nullptr, 0, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, R, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          site_seed(c, step, l, 2))))
+                          site_seed(c, step, l, 2), nullptr, nullptr, nullptr, c.eval_rows)))
             return rc;
         // --- context attention block (keys / values of the memory bank were projected once)
         if (fuse) {
@@ -946,23 +957,24 @@ static int step_fwd(const Ctx& c, int step) {
         DT_CALL(c, launch_attn_fwd, c, qc, d, mkv, mkv + (int64_t)d * es, (int64_t)p->Ls * NL * 2 * d,
                 (int64_t)NL * 2 * d, G.src_mask(), p->Ls, ctx2, d, p->Ls, pa, site_seed(c, step, l, 3));
         if ((rc = gemm_nt(c, ctx2, d, L.w_co, d, h2, d, R, d, d, L.b_co, 0, h1, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          site_seed(c, step, l, 4))))
+                          site_seed(c, step, l, 4), nullptr, nullptr, nullptr, c.eval_rows)))
             return rc;
         // --- feed forward block
         if (fuse) {
             if ((rc = gemm_nt(c, h2, d, L.wg_1, d, inter, ff, R, ff, d, L.bf_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
-                              pd, site_seed(c, step, l, 5), L.cs_1, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1))))
+                              pd, site_seed(c, step, l, 5), L.cs_1, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1),
+                              c.eval_rows)))
                 return rc;
         } else {
             if ((rc = mssr_layernorm_fwd(h2, L.lnf_g, L.lnf_b, n3, G.stat(l * 3 + 2, 0), G.stat(l * 3 + 2, 1), R, d,
                                          1e-6f, c.dt, c.s)))
                 return rc;
             if ((rc = gemm_nt(c, n3, d, L.w_1, d, inter, ff, R, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt,
-                              pd, site_seed(c, step, l, 5))))
+                              pd, site_seed(c, step, l, 5), nullptr, nullptr, nullptr, c.eval_rows)))
                 return rc;
         }
         if ((rc = gemm_nt(c, inter, ff, L.w_2, ff, G.X(l + 1), d, R, d, ff, L.b_2, 0, h2, d, nullptr, 0, 1.f, 0.f, c.dt,
-                          pd, site_seed(c, step, l, 6))))
+                          pd, site_seed(c, step, l, 6), nullptr, nullptr, nullptr, c.eval_rows)))
             return rc;
     }
     // final LayerNorm, generator Linear, softmax(/T)
@@ -1012,11 +1024,11 @@ static int step_bwd(const Ctx& c, int step) {
         if (c.dt == MSSR_F32)
             ln_bwd_dx_kernel<float><<<(R + 3) / 4, 256, 0, c.s>>>((const float*)dy, (const float*)x, g, G.stat(idx, 0),
                                                                  G.stat(idx, 1), (const float*)dres, (float*)dx,
-                                                                 (float*)dx2, R, d, pd, seed, extra);
+                                                                 (float*)dx2, R, d, pd, seed, extra, c.hash_row_off);
         else
             ln_bwd_dx_kernel<bf16><<<(R + 3) / 4, 256, 0, c.s>>>((const bf16*)dy, (const bf16*)x, g, G.stat(idx, 0),
                                                                 G.stat(idx, 1), (const bf16*)dres, (bf16*)dx,
-                                                                (bf16*)dx2, R, d, pd, seed, extra);
+                                                                (bf16*)dx2, R, d, pd, seed, extra, c.hash_row_off);
     };
 
     // softmax backward: dlogits[step] (compute dtype, padded columns stay zero)
@@ -1060,12 +1072,12 @@ static int step_bwd(const Ctx& c, int step) {
             ds.in_dtype = c.dt; ds.out_dtype = c.dt;
             ds.drop_p = 0.f; ds.drop_seed = 0;
             ds.workspace = nullptr; ds.workspace_bytes = 0; ds.no_skinny = 0;
-            ds.ln_colsum = nullptr; ds.ln_mean = nullptr; ds.ln_rstd = nullptr; ds.ln_eps = 0.f;
+            ds.ln_colsum = nullptr; ds.ln_mean = nullptr; ds.ln_rstd = nullptr; ds.ln_eps = 0.f; ds.drop_row0 = 0;
             GemmArgs a;
             gemm_fill_args(&ds, a);
             a.lnb_x = x; a.lnb_gamma = g; a.lnb_mean = G.stat(idx, 0); a.lnb_rstd = G.stat(idx, 1);
             a.lnb_dres = dres; a.lnb_dx = dxo; a.lnb_dx2 = dx2;
-            a.lnb_p = pd; a.lnb_extra = 1.f; a.lnb_seed = seed;
+            a.lnb_p = pd; a.lnb_extra = 1.f; a.lnb_seed = seed; a.lnb_row_off = c.hash_row_off;
             const int pi = prof_begin(c.s);
             const bool done = gemm_lnb_try(a, c.dt, c.s);
             prof_end(pi, c.s, 3, c.dt, c.dt, 32, 1, R, n, d, 1, 2);        // nothing launched: the record keeps ms = -1
@@ -1178,8 +1190,10 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
                          p->dctx && p->ds_self && p->ds_ctx && p->d_e && p->dnf,
                      "%s: null gradient buffer in plan", who);
     }
-    const int per = (p->B + p->n_chunks - 1) / p->n_chunks;
-    const int nch = (p->B + per - 1) / per;
+    // backward of a mixed sweep: ONE chunk = sentences [bwd_row0, B), addressed as a slice of the unchunked forward
+    const int row0 = backward ? p->bwd_row0 : 0;
+    const int per = row0 ? p->B - row0 : (p->B + p->n_chunks - 1) / p->n_chunks;
+    const int nch = row0 ? 1 : (p->B + per - 1) / per;
     Ctx cs[MAX_CHUNKS];
     StreamPool* P = nullptr;
     if (nch > 1) {
@@ -1191,7 +1205,9 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
     for (int i = 0; i < nch; ++i) {
         Ctx& c = cs[i];
         c.p = p; c.dt = p->dtype; c.es = dsize(p->dtype);
-        c.b0 = i * per; c.Bc = (c.b0 + per <= p->B) ? per : p->B - c.b0; c.chunk = i;
+        c.b0 = row0 + i * per; c.Bc = (c.b0 + per <= p->B) ? per : p->B - c.b0; c.chunk = i;
+        c.eval_rows = backward ? 0 : p->eval_rows;
+        c.hash_row_off = row0;
         c.ws = p->gemm_ws ? (char*)p->gemm_ws + i * ws_each : nullptr;
         c.ws_bytes = ws_each;
         c.s = stream;

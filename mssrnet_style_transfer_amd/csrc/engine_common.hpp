@@ -18,7 +18,8 @@ static inline char* at(void* base, int64_t elems, size_t es) { return (char*)bas
 static int gemm_nt(const GemmCtx& c, const void* a, int64_t lda, const void* w, int64_t ldw, void* out, int64_t ldc,
                    int64_t m, int64_t n, int64_t k, const float* bias, int relu, const void* residual, int64_t ldr,
                    const void* gate, int64_t ldg, float alpha, float beta, int out_dt, float drop_p, uint64_t seed,
-                   const float* ln_colsum = nullptr, float* ln_mean = nullptr, float* ln_rstd = nullptr) {
+                   const float* ln_colsum = nullptr, float* ln_mean = nullptr, float* ln_rstd = nullptr,
+                   int64_t drop_row0 = 0) {
     mssr_gemm_desc d;
     d.a = a; d.b = w; d.c = out; d.bias = bias; d.residual = residual; d.gate = gate;
     d.m = m; d.n = n; d.k = k;
@@ -28,7 +29,7 @@ static int gemm_nt(const GemmCtx& c, const void* a, int64_t lda, const void* w, 
     d.a_bo = d.a_bi = d.b_bo = d.b_bi = d.c_bo = d.c_bi = 0;
     d.alpha = alpha; d.beta = beta; d.relu = relu;
     d.in_dtype = c.dt; d.out_dtype = out_dt;
-    d.drop_p = drop_p; d.drop_seed = seed;
+    d.drop_p = drop_p; d.drop_seed = seed; d.drop_row0 = drop_row0;
     d.workspace = c.ws; d.workspace_bytes = c.ws_bytes; d.no_skinny = 0;
     d.ln_colsum = ln_colsum; d.ln_mean = ln_mean; d.ln_rstd = ln_rstd; d.ln_eps = 1e-6f;
     return mssr_gemm(&d, c.s);
@@ -44,7 +45,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, const T* __restrict__ dres,
                                                         T* __restrict__ dx, T* __restrict__ dx2, int rows, int d,
-                                                        float p, uint64_t seed, float extra) {
+                                                        float p, uint64_t seed, float extra, int row_off) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
         if (dres) V4<T>::load(dres + (int64_t)row * d + c, rr);
         uint32_t kp[2] = {3u, 3u};          // row * d + c is a multiple of 4 (vector loads): two whole decision pairs
         if (p > 0.f) {
-            const uint64_t i2 = ((uint64_t)row * d + c) >> 1;
+            const uint64_t i2 = ((uint64_t)(row + row_off) * d + c) >> 1;
             kp[0] = keep16_pair(seed, i2, thr);
             kp[1] = keep16_pair(seed, i2 + 1, thr);
         }
@@ -96,9 +97,9 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
 template <typename T>
 static void launch_ln_bwd_dx(hipStream_t s, const void* dy, const void* x, const float* g, const float* mean,
                              const float* rstd, const void* dres, void* dx, void* dx2, int rows, int d, float p,
-                             uint64_t seed, float extra) {
+                             uint64_t seed, float extra, int row_off = 0) {
     ln_bwd_dx_kernel<T><<<(rows + 3) / 4, 256, 0, s>>>((const T*)dy, (const T*)x, g, mean, rstd, (const T*)dres, (T*)dx,
-                                                      (T*)dx2, rows, d, p, seed, extra);
+                                                      (T*)dx2, rows, d, p, seed, extra, row_off);
 }
 
 }  // namespace mssr

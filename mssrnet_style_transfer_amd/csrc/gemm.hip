@@ -218,7 +218,7 @@ extern "C" int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch) { return use_
 
 void mssr::gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
     a.lnb_x = nullptr; a.lnb_gamma = a.lnb_mean = a.lnb_rstd = nullptr; a.lnb_dres = nullptr; a.lnb_dx = a.lnb_dx2 = nullptr;
-    a.lnb_p = 0.f; a.lnb_extra = 1.f; a.lnb_seed = 0;
+    a.lnb_p = 0.f; a.lnb_extra = 1.f; a.lnb_seed = 0; a.lnb_row_off = 0;
     a.a = d->a; a.b = d->b; a.c = d->c; a.bias = d->bias; a.residual = d->residual; a.gate = d->gate;
     a.m = d->m; a.n = d->n; a.k = d->k;
     a.a_rs = d->a_rs; a.a_cs = d->a_cs; a.b_rs = d->b_rs; a.b_cs = d->b_cs;
@@ -226,7 +226,7 @@ void mssr::gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
     a.batch_inner = d->batch_inner;
     a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
-    a.drop_p = d->drop_p; a.drop_seed = d->drop_seed;
+    a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.drop_row0 = d->drop_row0;
     a.ksplit = 1;
     a.partial = nullptr;
     if (d->workspace && d->k > 32 * 64) {

@@ -20,6 +20,7 @@ struct GemmArgs {
     int a_vec, b_vec;   // 16-B vector loads allowed for this operand
     float drop_p;       // > 0: dropout in the epilogue, keep = hash(seed, z*m*n + row*n + col) >= p*2^32
     uint64_t drop_seed;
+    int64_t drop_row0;  // rows below this one are NOT dropped (and not rescaled): eval-mode rows sharing a launch
     float* partial;     // skinny split-K: fp32 slabs [ksplit][m][n]
     int ksplit;
     // LayerNorm prologue (skinny kernel only): non-null ln_colsum switches it on
@@ -40,6 +41,7 @@ struct GemmArgs {
     void* lnb_dx2;
     float lnb_p, lnb_extra;
     uint64_t lnb_seed;
+    int64_t lnb_row_off;    // added to the row index in the dropout hash: the rows are a slice of the forward's rows
 };
 
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
@@ -52,7 +54,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float acc, int
                                                TO* C, const TI* R, const TI* G, int64_t zoff) {
     float v = p.alpha * acc + bias;
     if (p.relu) v = fmaxf(v, 0.f);
-    if (p.drop_p > 0.f)
+    if (p.drop_p > 0.f && row >= p.drop_row0)
         v = drop_keep(p.drop_seed, (uint64_t)(zoff + row * p.n + col), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
     if (R) v += to_f(R[row * p.ldr + col]);
     if (G) v = to_f(G[row * p.ldg + col]) > 0.f ? v : 0.f;

@@ -120,7 +120,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
         bf16x8 dxv, dx2v;
         uint32_t kp[4] = {3u, 3u, 3u, 3u};  // ar * K + k is a multiple of 8: four whole decision pairs
         if (p.lnb_p > 0.f) {
-            const uint64_t i2 = (uint64_t)(ar * p.k + k) >> 1;
+            const uint64_t i2 = (uint64_t)((ar + p.lnb_row_off) * p.k + k) >> 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) kp[q] = keep16_pair(p.lnb_seed, i2 + q, thr);
         }

@@ -185,7 +185,7 @@ def clear_pack_cache():
 class _Spec:
     """Everything about one decode call that is not a tensor autograd tracks."""
     __slots__ = ("pack", "B", "Ls", "T", "heads", "training", "p_drop", "p_attn", "temperature", "seed", "src_mask",
-                 "bos", "pe", "save")
+                 "bos", "pe", "save", "eval_rows")
 
 
 def _bgemm_t(dy, x):
@@ -240,6 +240,9 @@ def _make_plan(spec, mem):
     plan.p_drop, plan.p_attn, plan.temperature, plan.seed = spec.p_drop, spec.p_attn, spec.temperature, spec.seed
     plan.layers = pk.layers
     plan.fuse_ln = int(pk.fuse_ln and os.environ.get("MSSR_DECODE_FUSE_LN", "1") != "0")
+    plan.eval_rows = plan.bwd_row0 = int(spec.eval_rows)
+    if spec.eval_rows:
+        plan.n_chunks = 1
     for name in ("emb_t", "emb", "w_gen", "wt_gen", "b_gen", "lnF_g", "lnF_b") + (
             ("wg_gen", "cs_gen", "bf_gen") if pk.fuse_ln else ()):
         setattr(plan, name, getattr(pk, name).data_ptr())
@@ -280,6 +283,7 @@ class _SoftDecode(Function):
         R = T * B
         z = lambda *shape, dtype=cd: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        E0 = spec.eval_rows         # sentences [0, E0) ran in eval mode and carry no gradient: the sweep skips them
         g = dict(dprobs=dprobs.to(torch.float32).clone(memory_format=torch.contiguous_format),
                  dlogits=z(R, Vp), dX=e(2, B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
                  dctx=e(NL, 2, R, d), ds_self=e(NL, 2, T, B * H, T, dtype=torch.float32),
@@ -287,6 +291,11 @@ class _SoftDecode(Function):
                  d_e=e(R, d), dnf=e(R, d))
         for name, t in g.items():
             setattr(plan, name, t.data_ptr())
+        if E0:
+            # the slabs that are contracted over ALL (step, sentence) rows must hold zeros where the sweep writes nothing
+            for name in ("dqkv", "dactD", "dactF", "d_e", "dnf"):
+                t = g[name]
+                t.view(-1, T, B, t.shape[-1])[:, :, :E0].zero_()
         L.check(lib.mssr_decode_bwd(ctypes.byref(plan), L.stream()), "decode_bwd")
 
         actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
@@ -320,13 +329,18 @@ class _SoftDecode(Function):
             for which, rhs in ((0, actD[l, K_QC]), (1, g["dctx"][l, 1])):
                 ops.gemm(dsc[l, which].permute(1, 2, 3, 0), rhs.view(T, B, H, dh).permute(1, 2, 0, 3), False, cd,
                          out=dmem_kv[:, :, l, which].permute(0, 2, 1, 3))
-        dmem_kv = dmem_kv.view(B * Ls, NL * 2 * d)
-        gW_ckv = _bgemm_t(dmem_kv, bufs["mem"]).view(NL, 2 * d, d)
+        dmem_kv = dmem_kv.view(B * Ls, NL * 2 * d)[E0 * Ls:]            # rows of the sentences that carry gradient
+        gW_ckv = _bgemm_t(dmem_kv, bufs["mem"][E0 * Ls:]).view(NL, 2 * d, d)
         gb_ckv = _colsum(dmem_kv).view(NL, 2 * d)
         g_mem = None
         if ctx.needs_input_grad[1]:
             shape, dtype = ctx.mem_meta
-            g_mem = ops.gemm(dmem_kv, pk.w_ckv, False, cd).view(shape).to(dtype)
+            g_mem = torch.zeros(shape, dtype=dtype, device=dev) if E0 else None
+            gm = ops.gemm(dmem_kv, pk.w_ckv, False, cd).view((B - E0,) + tuple(shape[1:])).to(dtype)
+            if E0:
+                g_mem[E0:] = gm
+            else:
+                g_mem = gm
         # LayerNorm gains / biases: sum over all (step, sentence) rows
         parts = lib.mssr_layernorm_partial_rows(R)
         ws = e(2 * parts * d, dtype=torch.float32)
@@ -386,11 +400,18 @@ def _make_spec(model, cfg, memory_bank, src_lengths, steps, params):
     return spec
 
 
-def soft_decode(model, cfg, memory_bank, src_lengths, steps):
+def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0):
     """vocab_probs [steps, B, V] (float) of the step-wise soft decode of ``model`` over
-    ``memory_bank`` [Ls, B, d] (the bonded encoder states)."""
+    ``memory_bank`` [Ls, B, d] (the bonded encoder states).
+
+    ``eval_rows`` > 0: two decodes in one sweep -- sentences [0, eval_rows) are decoded in EVAL mode (no dropout) and
+    carry no gradient (the critics' fake text, onmt/trainer_wgan_wh.py:530-535), the rest follow ``model.training``
+    and are differentiable (the generator step's decodes, :917-920); see mssr_decode_plan.eval_rows."""
     params = decoder_params(model)
     spec = _make_spec(model, cfg, memory_bank, src_lengths, steps, params)
+    spec.eval_rows = int(eval_rows)
+    if not 0 <= spec.eval_rows < memory_bank.shape[1]:
+        raise ValueError("eval_rows must leave at least one differentiable sentence")
     needs = torch.is_grad_enabled() and (memory_bank.requires_grad or any(p.requires_grad for p in params))
     spec.save = bool(needs)
     mem = memory_bank.transpose(0, 1).contiguous()          # [B, Ls, d]
@@ -408,7 +429,7 @@ def greedy_decode_ids(model, cfg, memory_bank, src_lengths, max_length, check_ev
     params = decoder_params(model)
     with torch.no_grad():
         spec = _make_spec(model, cfg, memory_bank, src_lengths, max_length, params)
-        spec.training, spec.save, spec.temperature = False, False, 1.0
+        spec.training, spec.save, spec.temperature, spec.eval_rows = False, False, 1.0, 0
         plan, bufs = _make_plan(spec, memory_bank.transpose(0, 1).contiguous())
         ids = torch.zeros(spec.T, spec.B, dtype=torch.int32, device=memory_bank.device)
         plan.ids, plan.greedy = ids.data_ptr(), 1

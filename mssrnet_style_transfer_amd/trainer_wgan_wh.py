@@ -229,7 +229,9 @@ class Trainer:
             o.step(self.cfg.max_grad_norm if clip else 0.0)
 
     # ------------------------------------------------------------------ phases
-    def train_discriminator(self, batch):
+    def train_discriminator(self, batch, _shared=None):
+        """``_shared`` = (style representation, fake-text probabilities) computed by train_wgan_step in the sweep it
+        shares with the generator phase; None: computed here, as the reference does (:530-535)."""
         cfg = self.cfg
         self.style_generator.eval()
         self.model.eval()
@@ -245,16 +247,22 @@ class Trainer:
         alpha_t, alpha_s = torch.rand(B, 1, 1), torch.rand(B, 1, 1)       # in the order the reference draws them
         # The generator side is in eval mode: its style representation is deterministic, so the reference's two
         # no_grad calls (:533 for the fake text, :571 for the fake style) are one here.
-        with torch.no_grad():
-            rep = self._gen_style_represents(labels, real_src, real_len)
+        if _shared is not None:
+            rep = _shared[0]
+        else:
+            with torch.no_grad():
+                rep = self._gen_style_represents(labels, real_src, real_len)
         real_rep_t = self._gen_real_style_represents(real_src, real_len).transpose(0, 1)
         gen_rep_t = rep.transpose(0, 1)
 
         # text critic: real / fake / gradient penalty
         gain_t_real = cal_disc_loss(self._call_text_discriminator(vocab_target, text_len), labels_list).mean()
         gain_t_real.backward(self.mone)
-        with torch.no_grad():
-            probs, _, _ = self._dynamic_decoding(real_src, real_len, rep, vocab_target.size(0))
+        if _shared is not None:
+            probs = _shared[1]
+        else:
+            with torch.no_grad():
+                probs, _, _ = self._dynamic_decoding(real_src, real_len, rep, vocab_target.size(0))
         gain_t_fake = cal_disc_loss(self._call_text_discriminator(probs, text_len), labels_list).mean()
         gain_t_fake.backward(self.one)
         with torch.no_grad():
@@ -283,7 +291,34 @@ class Trainer:
                         lambda d: dict(T_cost=d["TF_gain"] - d["TR_gain"] + d["T_gp"], T_Wgap=d["TR_gain"] - d["TF_gain"],
                                        S_cost=d["SF_gain"] - d["SR_gain"] + d["S_gp"], S_Wgap=d["SR_gain"] - d["SF_gain"]))
 
-    def _train_generator_batched(self, batch):
+    def _generator_forward_batched(self, labels, real_src, real_len, tgt_len, eval_prefix=None):
+        """Style representations, bonded encoder states and ONE soft decode for both halves of the generator phase
+        (adversarial text: desired style, tgt_len + 10 steps; self-style text: own style, tgt_len steps).
+        ``eval_prefix`` = (memory bank [Ls, B, d], lengths) of sentences to decode in the same sweep in eval mode
+        without gradient (the critics' fake text): returns their probabilities as well."""
+        cfg = self.cfg
+        B = real_len.numel()
+        desired = 1 - labels
+        max_dec_steps = tgt_len + cfg.max_extra_dec_steps
+        rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1),
+                                             real_len.repeat(3))
+        rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
+        src2, len2 = real_src.repeat(1, 2, 1), real_len.repeat(2)
+        enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep, rep3], 1))
+        fake = None
+        if eval_prefix is None:
+            self.model.decoder.init_state(src2, mem, enc_state)
+            probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
+        else:
+            mem_e, len_e = eval_prefix
+            E = len_e.numel()
+            self.model.decoder.init_state(real_src.repeat(1, 3, 1), None, None)
+            both = soft_decode(self.model, cfg, torch.cat([mem_e.to(mem.dtype), mem], 1), torch.cat([len_e, len2]),
+                               max_dec_steps, eval_rows=E)
+            fake, probs_all = both[:tgt_len, :E].detach(), both[:, E:]
+        return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], fake
+
+    def _train_generator_batched(self, batch, _shared=None):
         """train_generator with its independent pieces batched (cfg.batch_generator_phase): the reference
         runs the style generator three times and encoder + soft decode twice on the SAME weights and source
         (onmt/trainer_wgan_wh.py:898-968); here they are one style-generator call on 3B rows and one
@@ -297,14 +332,10 @@ class Trainer:
         desired = 1 - labels
         desired_list = desired
         max_dec_steps = tgt_len + cfg.max_extra_dec_steps
-        rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1),
-                                             real_len.repeat(3))
-        rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
-        src2, len2 = real_src.repeat(1, 2, 1), real_len.repeat(2)
-        enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep, rep3], 1))
-        self.model.decoder.init_state(src2, mem, enc_state)
-        probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
-        probs, sprobs = probs_all[:, :B], probs_all[:tgt_len, B:]
+        if _shared is not None:
+            rep2, probs, sprobs = _shared
+        else:
+            rep2, probs, sprobs, _ = self._generator_forward_batched(labels, real_src, real_len, tgt_len)
         seq_lens, _ = dec_output_length(probs, cfg)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
         gain_t = cal_disc_loss(self._call_text_discriminator(probs, lens), desired_list).mean()
@@ -318,16 +349,46 @@ class Trainer:
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
         return PhaseLog(("AT_gain", "AT_acc", "AS_gain", "T_selfstyle_vloss"), (gain_t, acc, gain_s, vl))
 
-    def train_generator(self, batch):
+    def train_wgan_step(self, batch):
+        """``train_discriminator(batch)`` then ``train_generator(batch)`` -- one WGAN step -- with the same results
+        as the two calls (same weights read, same order of optimizer updates; the bits of the critics' fake text are
+        unchanged, the generator's dropout masks differ as between any two runs) and ONE decode sweep instead of two:
+        the critics' fake text (eval mode, no gradient, tgt_len steps; onmt/trainer_wgan_wh.py:530-535) and the
+        generator phase's two decodes (train mode, :917-920, :955-968) read the same generator weights, and a
+        sweep's cost is its ~100 dependent launches per step, not its row count.  Returns (d_log, g_log)."""
+        cfg = self.cfg
+        if not (cfg.ap_gen_self_style_text and cfg.batch_generator_phase and cfg.share_decode_sweep):
+            return self.train_discriminator(batch), self.train_generator(batch)
+        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        tgt_len = vocab_target.size(0)
+        # generator side in eval mode: what train_discriminator computes under no_grad (:530-535)
+        self.style_generator.eval()
+        self.model.eval()
+        with torch.no_grad():
+            rep_d = self._gen_style_represents(labels, real_src, real_len)
+            _, mem_d, _ = self._encode(real_src, real_len, rep_d)
+        # generator side in train mode: the forward half of train_generator, decode shared with the rows above
+        self.style_generator.train()
+        self.model.train()
+        self.style_generator_optim.zero_grad()
+        self.model_optim.zero_grad()
+        rep2, probs, sprobs, fake = self._generator_forward_batched(labels, real_src, real_len, tgt_len,
+                                                                   eval_prefix=(mem_d, real_len))
+        d_log = self.train_discriminator(batch, _shared=(rep_d, fake))
+        g_log = self.train_generator(batch, _shared=(rep2, probs, sprobs))
+        return d_log, g_log
+
+    def train_generator(self, batch, _shared=None):
         cfg = self.cfg
         self.style_generator.train()
         self.model.train()
         self.style_discriminator.eval()
         self.text_discriminator.eval()
-        self.style_generator_optim.zero_grad()
-        self.model_optim.zero_grad()
+        if _shared is None:
+            self.style_generator_optim.zero_grad()
+            self.model_optim.zero_grad()
         if cfg.ap_gen_self_style_text and cfg.batch_generator_phase:
-            return self._train_generator_batched(batch)
+            return self._train_generator_batched(batch, _shared)
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
         tgt_len, B = vocab_target.size(0), vocab_target.size(1)
         desired = 1 - labels                                   # num_styles == 2 (train_and_translate.py:72-73)

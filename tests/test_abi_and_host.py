@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), "libmssr_hip.so does not export %s" % n
         assert n in _lib.SIGNATURES, "no ctypes signature for %s" % n
     assert set(_lib.SIGNATURES) <= set(names)
-    assert _lib.load().mssr_abi_version() == 1
+    assert _lib.load().mssr_abi_version() == 2
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -35,7 +35,7 @@ def gp_probe(g):
 def test_library_loads_and_reports_errors():
     from mssrnet_style_transfer_amd import _lib
     lib = _lib.load()
-    assert lib.mssr_abi_version() == 1
+    assert lib.mssr_abi_version() == 2
     x = torch.zeros(4, 6, device="cuda")     # d = 6 is not a multiple of 4 -> rejected, nothing launched
     rc = lib.mssr_layernorm_fwd(x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
                                 4, 6, 1e-6, 0, None)

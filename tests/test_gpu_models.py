@@ -289,6 +289,7 @@ def test_training_loop_learns_and_keeps_memory_flat(ops):
         if i in (9, 39):
             torch.cuda.synchronize()
             mem.append(torch.cuda.memory_allocated())
+    ops.set_compute_dtype(torch.float32)
     for k in (0, 1):
         assert last[k] < 0.8 * first[k], (k, first[k], last[k])
     assert mem[1] <= mem[0] * 1.05 + (1 << 20), mem
@@ -334,3 +335,81 @@ def test_decoder_map_state_compacts_the_cache(ops):
     for s in range(5):
         a = cut[s] if s > 1 else cut[s].index_select(0, keep)
         assert_close(a, ref[s], 1e-4, "step %d" % s)
+
+
+def test_wgan_step_with_shared_decode_sweep_equals_the_two_phases(ops, golden_phases):
+    """Trainer.train_wgan_step (the critics' fake text decoded in eval mode in the same sweep as the generator
+    phase's texts: mssr_decode_plan.eval_rows / bwd_row0) against train_discriminator + train_generator called one
+    after the other: same logged scalars, same gradients of all four networks, same parameters after the two
+    optimizer steps (fp32, dropout 0 -> the only difference is the row grouping of the launches)."""
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    ops.set_compute_dtype(torch.float32)
+    cfg = MSSRConfig.small()
+    runs = []
+    for shared in (False, True):
+        nets = make_nets(golden_phases, cfg.with_(share_decode_sweep=shared))
+        tr = Trainer(nets, cfg.with_(share_decode_sweep=shared))
+        torch.manual_seed(5)
+        random.seed(5)
+        d_log, g_log = tr.train_wgan_step(gpu_batch(golden_phases))
+        runs.append((dict(d_log), dict(g_log), nets))
+    (d0, g0, n0), (d1, g1, n1) = runs
+    c = golden_phases["discriminator"]          # the critics' half still equals the reference's phase
+    for k, v in d0.items():
+        assert abs(d1[k] - v) <= 1e-6 * max(abs(v), 1e-3), ("D", k, d1[k], v)
+    for k, v in g0.items():
+        assert abs(g1[k] - v) <= 1e-5 * max(abs(v), 1e-3), ("G", k, g1[k], v)
+    for name in ("text_discriminator", "style_discriminator", "model", "style_generator"):
+        assert_grads(grads_of(n1[name]), {k: g for k, g in grads_of(n0[name]).items()}, 2e-5, "shared." + name)
+        # Adam turns a mathematically-zero gradient (rounding noise, e.g. the key-projection bias) into a step of
+        # arbitrary sign: every element within 2 lr, as helpers.assert_post_step allows
+        for (k, a), (_, b) in zip(n0[name].named_parameters(), n1[name].named_parameters()):
+            assert float((a - b).abs().max()) <= 2.05 * cfg.learning_rate + 1e-7, "post-step %s.%s" % (name, k)
+    assert set(c["scalars"]) <= set(d1)
+
+
+def test_mixed_eval_train_sweep_with_dropout(ops):
+    """eval_rows sentences of a mixed sweep must be decoded WITHOUT dropout (bit-identical to an eval-mode decode of
+    the same sentences) while the rest are dropped, and the backward over the differentiable sentences must replay
+    exactly the masks their forward drew (finite-difference check of a seed-fixed loss along a random direction)."""
+    from mssrnet_style_transfer_amd import style_generator_builder as SB
+    from mssrnet_style_transfer_amd import ops as O
+    from mssrnet_style_transfer_amd.decode_engine import soft_decode
+    ops.set_compute_dtype(torch.float32)
+    cfg = MSSRConfig.small(dropout=0.3, attention_dropout=0.2)
+    torch.manual_seed(11)
+    model = SB.build_main_model(cfg).cuda()
+    Ls, E, G, T = 6, 3, 4, 5
+    mem = torch.randn(Ls, E + G, cfg.d_model, device="cuda")
+    lens = torch.tensor([6, 5, 4, 6, 6, 3, 2], device="cuda")
+    model.eval()
+    with torch.no_grad():
+        want_eval = soft_decode(model, cfg, mem[:, :E].contiguous(), lens[:E], T)
+    model.train()
+
+    def run(m):
+        O._state["seed_counter"] = 4321         # same dropout seeds on every call
+        return soft_decode(model, cfg, m, lens, T, eval_rows=E)
+
+    with torch.no_grad():
+        both = run(mem)
+        assert torch.equal(run(mem), both), "same seed must give the same masks"
+    assert torch.equal(both[:, :E], want_eval)
+    model.eval()
+    with torch.no_grad():
+        all_eval = soft_decode(model, cfg, mem, lens, T)
+    model.train()
+    assert float((both[:, E:] - all_eval[:, E:]).abs().max()) > 1e-4          # the other sentences ARE dropped
+    w = torch.randn(T, E + G, cfg.vocab_size, device="cuda")
+    m1 = mem.clone().requires_grad_(True)
+    loss = (run(m1) * w).sum()
+    g, = torch.autograd.grad(loss, m1)
+    assert float(g[:, :E].abs().max()) == 0.0                                  # eval sentences carry no gradient
+    # along the gradient itself: the best conditioned finite difference (see test_engine_dropout_backward_replays_masks)
+    direction = g / g.norm() * float(g[:, E:].numel()) ** 0.5
+    analytic = float((g * direction).sum())
+    # (ReLU / dropout kinks make the difference quotient drift at larger steps: 2e-3 is off by up to 6 % here, 5e-4 by 3e-4)
+    eps = 5e-4
+    with torch.no_grad():
+        fd = float((((run(mem + eps * direction) - run(mem - eps * direction)) * w).sum() / (2 * eps)).double())
+    assert abs(fd - analytic) <= 1e-2 * max(abs(fd), 1e-3), (fd, analytic)
