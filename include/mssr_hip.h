@@ -104,6 +104,12 @@ typedef struct {
     /* rows below drop_row0 are exempt from the epilogue dropout (kept, not rescaled): eval-mode rows that share a
      * launch with training-mode rows (mssr_decode_plan.eval_rows).  0 = every row is dropped as drop_p says. */
     int64_t drop_row0;
+    /* Segmented reduction index, for weight gradients over the rows of a [T][B, .] slab that skip the first sentences of
+     * every step block (mssr_decode_plan.bwd_row0): logical k = s * k_seg_len + j (j < k_seg_len) is read at physical
+     * k index s * k_seg_stride + j of BOTH operands (their pointers already point at the first wanted row); `k` is
+     * the logical length.  Only the weight-gradient form (bf16, A m-contiguous, B n-contiguous, plain epilogue) takes
+     * it; 0 / 0 = plain. */
+    int64_t k_seg_len, k_seg_stride;
 } mssr_gemm_desc;
 int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
 /* mssr_gemm for callers that CANNOT ALLOCATE -- code under HIP graph capture, tight serving loops, harnesses that

@@ -30,7 +30,7 @@ class GemmDesc(Structure):
                 ("drop_p", c_float), ("drop_seed", c_uint64),
                 ("workspace", c_void_p), ("workspace_bytes", c_int64), ("no_skinny", c_int),
                 ("ln_colsum", c_void_p), ("ln_mean", c_void_p), ("ln_rstd", c_void_p), ("ln_eps", c_float),
-                ("drop_row0", c_int64)]
+                ("drop_row0", c_int64), ("k_seg_len", c_int64), ("k_seg_stride", c_int64)]
 
 
 class DecLayer(Structure):

@@ -1061,7 +1061,7 @@ static int step_bwd(const Ctx& c, int step) {
         void* dxo = first ? dxb[cur] : dxb[cur ^ 1];
         if (!first) cur ^= 1;
         if (fuse_lnb) {
-            mssr_gemm_desc ds;
+            mssr_gemm_desc ds = {};
             ds.a = dy; ds.b = w; ds.c = out; ds.bias = nullptr; ds.residual = nullptr; ds.gate = gate;
             ds.m = R; ds.n = n; ds.k = d;
             ds.a_rs = d; ds.a_cs = 1; ds.b_rs = 1; ds.b_cs = ldw;

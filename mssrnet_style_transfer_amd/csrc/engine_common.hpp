@@ -20,7 +20,7 @@ static int gemm_nt(const GemmCtx& c, const void* a, int64_t lda, const void* w, 
                    const void* gate, int64_t ldg, float alpha, float beta, int out_dt, float drop_p, uint64_t seed,
                    const float* ln_colsum = nullptr, float* ln_mean = nullptr, float* ln_rstd = nullptr,
                    int64_t drop_row0 = 0) {
-    mssr_gemm_desc d;
+    mssr_gemm_desc d = {};
     d.a = a; d.b = w; d.c = out; d.bias = bias; d.residual = residual; d.gate = gate;
     d.m = m; d.n = n; d.k = k;
     d.a_rs = lda; d.a_cs = 1; d.b_rs = 1; d.b_cs = ldw;

@@ -227,6 +227,7 @@ void mssr::gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
     a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
     a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.drop_row0 = d->drop_row0;
+    a.k_seg_len = d->k_seg_len; a.k_seg_stride = d->k_seg_stride;
     a.ksplit = 1;
     a.partial = nullptr;
     if (d->workspace && d->k > 32 * 64) {
@@ -270,10 +271,20 @@ static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
     MSSR_REQUIRE((d->m + 31) / 32 <= 65535, "%s: m too large", who);
 
     MSSR_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, "%s: drop_p=%f out of [0,1)", who, d->drop_p);
+    MSSR_REQUIRE((d->k_seg_len == 0 && d->k_seg_stride == 0) || (d->k_seg_len > 0 && d->k_seg_stride >= d->k_seg_len),
+                 "%s: bad k segmentation (len %lld, stride %lld)", who, (long long)d->k_seg_len, (long long)d->k_seg_stride);
     GemmArgs a;
     gemm_fill_args(d, a);
     hipStream_t s = (hipStream_t)stream;
     const int pi = prof_begin(s);
+    if (d->k_seg_len > 0) {         // only the weight-gradient kernel walks a segmented k
+        if (!d->no_skinny && gemm_tn_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+            prof_end(pi, s, 2, d->in_dtype, d->out_dtype, 64, batch, d->m, d->n, d->k);
+            MSSR_LAUNCH_OK("gemm(tn)");
+        }
+        set_error("%s: a segmented k needs the weight-gradient form (bf16, A m-contiguous, B n-contiguous, plain epilogue)", who);
+        return MSSR_ERR_UNSUPPORTED;
+    }
     if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {
         prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_tile(d->m, d->n, d->k), batch, d->m, d->n, d->k,
                  gemm_skinny_ksplit(d->k), d->ln_colsum ? 1 : 0);

@@ -21,6 +21,7 @@ struct GemmArgs {
     float drop_p;       // > 0: dropout in the epilogue, keep = hash(seed, z*m*n + row*n + col) >= p*2^32
     uint64_t drop_seed;
     int64_t drop_row0;  // rows below this one are NOT dropped (and not rescaled): eval-mode rows sharing a launch
+    int64_t k_seg_len, k_seg_stride;    // segmented reduction index (weight-gradient kernel only), 0 = plain
     float* partial;     // skinny split-K: fp32 slabs [ksplit][m][n]
     int ksplit;
     // LayerNorm prologue (skinny kernel only): non-null ln_colsum switches it on

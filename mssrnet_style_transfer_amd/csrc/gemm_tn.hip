@@ -27,6 +27,7 @@ struct TnArgs {
     float alpha, beta;
     int a_vec, b_vec;
     int ksplit;         // > 1: blockIdx.z = batch * ksplit + slice, fp32 C pre-set (zero or beta*C), partial sums by atomics
+    int64_t seg_len, seg_stride;    // > 0: logical k = s*seg_len + j lives at physical row s*seg_stride + j (mssr_gemm_desc.k_seg_len)
 };
 
 // one [TN_BK][W] tile: every thread owns W*TN_BK/8/256 chunks of 8 elements
@@ -37,8 +38,9 @@ struct TnLoader {
     static constexpr int LD = W + 8;                 // +16 B per row
     s16x8 reg[NCH];
 
+    // krow0 = physical row of logical row k0; rows kk >= rem of the tile lie in the next segment, `jump` rows further on
     __device__ __forceinline__ void fetch(const bf16* __restrict__ src, int64_t ld, int64_t k0, int64_t c0, int64_t K,
-                                          int64_t cols, bool vec) {
+                                          int64_t cols, bool vec, int64_t krow0, int rem, int64_t jump) {
 #pragma unroll
         for (int i = 0; i < NCH; ++i) {
             const int idx = i * TN_THREADS + threadIdx.x;
@@ -47,7 +49,8 @@ struct TnLoader {
                 const int kk = idx / (W / 8), cc = (idx % (W / 8)) * 8;
                 const int64_t gk = k0 + kk, gc = c0 + cc;
                 if (gk < K && gc < cols) {
-                    const bf16* p = src + gk * ld + gc;
+                    const int64_t row = krow0 + kk + (kk >= rem ? jump : 0);
+                    const bf16* p = src + row * ld + gc;
                     if (vec && gc + 8 <= cols) {
                         v = *reinterpret_cast<const s16x8*>(p);
                     } else {
@@ -111,15 +114,31 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs p) {
     const int64_t nk_all = (p.k + TN_BK - 1) / TN_BK;
     const int64_t per = (nk_all + p.ksplit - 1) / p.ksplit;            // k-tiles of this slice
     const int64_t t_begin = zs * per, nk = t_begin + per < nk_all ? t_begin + per : nk_all;
-    la.fetch(A, p.lda, t_begin * TN_BK, m0, p.k, p.m, p.a_vec);
-    lb.fetch(B, p.ldb, t_begin * TN_BK, n0, p.k, p.n, p.b_vec);
+    // segmented k (seg_len >= TN_BK, so a tile crosses at most one segment boundary): uniform 32-bit arithmetic per tile
+    const int64_t jump = p.seg_stride - p.seg_len;
+    int64_t krow0;
+    int rem;
+    auto locate = [&](int64_t k0) {
+        if (p.seg_len > 0) {
+            const uint32_t sg = (uint32_t)k0 / (uint32_t)p.seg_len, j = (uint32_t)k0 - sg * (uint32_t)p.seg_len;
+            krow0 = (int64_t)sg * p.seg_stride + j;
+            rem = (int)((uint32_t)p.seg_len - j);
+        } else {
+            krow0 = k0;
+            rem = 1 << 30;
+        }
+    };
+    locate(t_begin * TN_BK);
+    la.fetch(A, p.lda, t_begin * TN_BK, m0, p.k, p.m, p.a_vec, krow0, rem, jump);
+    lb.fetch(B, p.ldb, t_begin * TN_BK, n0, p.k, p.n, p.b_vec, krow0, rem, jump);
     for (int64_t t = t_begin; t < nk; ++t) {
         la.commit(As);
         lb.commit(Bs);
         __syncthreads();
         if (t + 1 < nk) {
-            la.fetch(A, p.lda, (t + 1) * TN_BK, m0, p.k, p.m, p.a_vec);
-            lb.fetch(B, p.ldb, (t + 1) * TN_BK, n0, p.k, p.n, p.b_vec);
+            locate((t + 1) * TN_BK);
+            la.fetch(A, p.lda, (t + 1) * TN_BK, m0, p.k, p.m, p.a_vec, krow0, rem, jump);
+            lb.fetch(B, p.ldb, (t + 1) * TN_BK, n0, p.k, p.n, p.b_vec, krow0, rem, jump);
         }
         bf16x8 fa[F], fb[F];
 #pragma unroll
@@ -167,6 +186,8 @@ bool gemm_tn_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, 
     t.batch_inner = g.batch_inner;
     t.a_bo = g.a_bo; t.a_bi = g.a_bi; t.b_bo = g.b_bo; t.b_bi = g.b_bi; t.c_bo = g.c_bo; t.c_bi = g.c_bi;
     t.alpha = g.alpha; t.beta = g.beta;
+    if (g.k_seg_len > 0 && (g.k_seg_len < TN_BK || g.k >= (int64_t)1 << 31 || g.k_seg_stride >= (int64_t)1 << 31)) return false;
+    t.seg_len = g.k_seg_len; t.seg_stride = g.k_seg_stride;
     t.a_vec = aligned(g.a, 16) && g.a_cs % 8 == 0 && g.a_bo % 8 == 0 && g.a_bi % 8 == 0;
     t.b_vec = aligned(g.b, 16) && g.b_rs % 8 == 0 && g.b_bo % 8 == 0 && g.b_bi % 8 == 0;
     const int64_t tiles64 = ((g.m + 63) / 64) * ((g.n + 63) / 64) * batch;

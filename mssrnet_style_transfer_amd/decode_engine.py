@@ -188,8 +188,13 @@ class _Spec:
                  "bos", "pe", "save", "eval_rows")
 
 
-def _bgemm_t(dy, x):
-    """sum over rows of dy[.., R, n]^T x[.., R, k] -> float [.., n, k] (a weight gradient)."""
+def _bgemm_t(dy, x, seg=None):
+    """sum over rows of dy[.., R, n]^T x[.., R, k] -> float [.., n, k] (a weight gradient).  seg = (T, B, E0): the
+    rows are T blocks of B, and only rows E0.. of every block take part (the others carry no gradient)."""
+    if seg is not None and seg[2] > 0 and dy.dtype == torch.bfloat16 and seg[1] - seg[2] >= 32:
+        T, B, E0 = seg
+        return ops.gemm(dy[..., E0:, :].transpose(-1, -2), x[..., E0:, :], False, torch.float32,
+                        k_seg=(B - E0, B, T))
     return ops.gemm(dy.transpose(-1, -2), x, False, torch.float32)
 
 
@@ -300,6 +305,7 @@ class _SoftDecode(Function):
 
         actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
         stats = bufs["stats"]
+        seg = (T, B, E0)
         if plan.fuse_ln:
             # the forward normalised inside the projections: materialise LN outputs once, over all steps' rows
             sm, sr = e(R, dtype=torch.float32), e(R, dtype=torch.float32)
@@ -313,12 +319,12 @@ class _SoftDecode(Function):
                 ln_fwd(actD[l, K_H1], pk.ln2_g[l], pk.ln2_b[l], actD[l, K_N2])
                 ln_fwd(actD[l, K_H2], pk.lnf_g[l], pk.lnf_b[l], actD[l, K_N3])
             ln_fwd(X[NL], pk.lnF_g, pk.lnF_b, bufs["nf"])
-        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, K_N1]), _bsum(dqkv)
-        gW_so, gb_so = _bgemm_t(dactD[:, G_DSO], actD[:, K_CTX1]), _bsum(dactD[:, G_DSO])
-        gW_cq, gb_cq = _bgemm_t(dactD[:, G_DCQ], actD[:, K_N2]), _bsum(dactD[:, G_DCQ])
-        gW_co, gb_co = _bgemm_t(dactD[:, G_DCO], actD[:, K_CTX2]), _bsum(dactD[:, G_DCO])
-        gW_1, gb_1 = _bgemm_t(dactF, actD[:, K_N3]), _bsum(dactF)
-        gW_2, gb_2 = _bgemm_t(dactD[:, G_DF2], actF), _bsum(dactD[:, G_DF2])
+        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, K_N1], seg), _bsum(dqkv)
+        gW_so, gb_so = _bgemm_t(dactD[:, G_DSO], actD[:, K_CTX1], seg), _bsum(dactD[:, G_DSO])
+        gW_cq, gb_cq = _bgemm_t(dactD[:, G_DCQ], actD[:, K_N2], seg), _bsum(dactD[:, G_DCQ])
+        gW_co, gb_co = _bgemm_t(dactD[:, G_DCO], actD[:, K_CTX2], seg), _bsum(dactD[:, G_DCO])
+        gW_1, gb_1 = _bgemm_t(dactF, actD[:, K_N3], seg), _bsum(dactF)
+        gW_2, gb_2 = _bgemm_t(dactD[:, G_DF2], actF, seg), _bsum(dactD[:, G_DF2])
         # gradient of the memory keys / values: contract the per-step score gradients over the steps,
         #   dK_mem[b,h,l,:] = sum_s ds_s[b,h,l] qc_s[b,h,:] ,  dV_mem[b,h,l,:] = sum_s pd_s[b,h,l] dctx2_s[b,h,:]
         # (one batched product per layer and operand), then the K|V projections in one product over all layers
@@ -360,9 +366,9 @@ class _SoftDecode(Function):
         ln_grad(3 * NL, g["dnf"], X[NL], pk.lnF_g)
         # generator and (soft) embedding table
         dlg = g["dlogits"][:, :V]
-        gW_gen = _bgemm_t(dlg, bufs["nf"])
+        gW_gen = _bgemm_t(dlg, bufs["nf"], seg)
         gb_gen = _colsum(dlg)
-        gE = _bgemm_t(bufs["in_all"][:T].view(R, Vp)[:, :V], g["d_e"])
+        gE = _bgemm_t(bufs["in_all"][:T].view(R, Vp)[:, :V], g["d_e"], seg)
 
         out = [None, g_mem, gE, ln_g[3 * NL, 0], ln_g[3 * NL, 1], gW_gen, gb_gen]
         for l in range(NL):

@@ -178,7 +178,7 @@ def _workspace(device):
 
 
 def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, alpha=1.0, out=None, beta=0.0,
-         drop_p=0.0, drop_seed=0, no_skinny=False, ln=None):
+         drop_p=0.0, drop_seed=0, no_skinny=False, ln=None, k_seg=None):
     """out[..., M, N] = epilogue(alpha * a[..., M, K] @ (b[..., N, K]^T if tb else b[..., K, N])).
     ln = (colsum [N], mean_out [M] or None, rstd_out [M] or None, eps): LayerNorm prologue of the
     skinny kernel (see mssr_gemm_desc.ln_colsum)."""
@@ -223,6 +223,11 @@ def gemm(a, b, tb, out_dtype, bias=None, relu=False, residual=None, gate=None, a
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     if ln is not None:
         d.ln_colsum, d.ln_mean, d.ln_rstd, d.ln_eps = ln[0].data_ptr(), L.ptr(ln[1]), L.ptr(ln[2]), float(ln[3])
+    if k_seg is not None:       # (segment length, segment stride, segments): see mssr_gemm_desc.k_seg_len
+        seg_len, seg_stride, n_seg = k_seg
+        if (n_seg - 1) * seg_stride + seg_len > k:
+            raise ValueError("k segmentation reaches beyond the operands")
+        d.k, d.k_seg_len, d.k_seg_stride = n_seg * seg_len, seg_len, seg_stride
     L.check(L.load().mssr_gemm(d, L.stream()), "gemm")
     return out
 
