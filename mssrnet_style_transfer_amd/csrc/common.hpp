@@ -26,6 +26,16 @@ inline void klaunch(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned shme
     else kern<<<grid, block, shmem, s>>>(args...);
 }
 
+// A launch with explicit profiling events (either may be null): products that take two launches -- split-K main kernel
+// + reduction, memset + atomic accumulation -- hand the record's start event to the first and its stop event to the
+// last, so the record covers the whole product.
+template <typename... KArgs, typename... Args>
+inline void klaunch_events(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, hipEvent_t e0,
+                           hipEvent_t e1, Args... args) {
+    if (e0 || e1) hipExtLaunchKernelGGL(kern, grid, block, shmem, s, e0, e1, 0, args...);
+    else kern<<<grid, block, shmem, s>>>(args...);
+}
+
 #define MSSR_REQUIRE(cond, ...)                 \
     do {                                        \
         if (!(cond)) {                          \

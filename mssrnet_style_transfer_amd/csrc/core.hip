@@ -60,6 +60,7 @@ extern "C" int mssr_prof_start(int max_records) {
     ProfState& P = g_prof;
     MSSR_REQUIRE(!P.on, "prof_start: already recording");
     MSSR_REQUIRE(max_records > 0 && max_records <= (1 << 20), "prof_start: bad record count");
+    delete[] P.rec;                  // records of the previous start/stop cycle (kept for mssr_prof_get until now)
     P.ev = new hipEvent_t[2 * (size_t)max_records];
     P.rec = new mssr_prof_record[max_records];
     for (int i = 0; i < 2 * max_records; ++i) {

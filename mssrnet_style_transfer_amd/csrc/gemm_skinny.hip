@@ -226,29 +226,33 @@ static int skinny_group(const GemmArgs& a, int tile) {
 }
 
 template <typename TO, bool LN, int F>
-static void skinny_launch_g(const GemmArgs& a, const dim3 grid, int group, hipStream_t s) {
-    if (group == 8) klaunch(gemm_skinny_kernel<TO, LN, F, 8>, grid, dim3(SK_THREADS), 0, s, a);
-    else if (group == 12) klaunch(gemm_skinny_kernel<TO, LN, F, 12>, grid, dim3(SK_THREADS), 0, s, a);
-    else klaunch(gemm_skinny_kernel<TO, LN, F, 4>, grid, dim3(SK_THREADS), 0, s, a);
+static void skinny_launch_g(const GemmArgs& a, const dim3 grid, int group, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (group == 8) klaunch_events(gemm_skinny_kernel<TO, LN, F, 8>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    else if (group == 12) klaunch_events(gemm_skinny_kernel<TO, LN, F, 12>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    else klaunch_events(gemm_skinny_kernel<TO, LN, F, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
 }
 
 template <typename TO>
 static void skinny_launch(const GemmArgs& a, hipStream_t s) {
     const int tile = gemm_skinny_tile(a.m, a.n, a.k);
+    // profiling: the record spans the whole product -- with split-K, from the main kernel's begin to the reduction's end
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)prof_take(&e0, &e1);
+    hipEvent_t e1_main = a.ksplit > 1 ? nullptr : e1;
     if (tile == 16) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
         const int g = skinny_group(a, tile);
-        if (a.ln_colsum) skinny_launch_g<TO, true, 1>(a, grid, g, s);
-        else skinny_launch_g<TO, false, 1>(a, grid, g, s);
+        if (a.ln_colsum) skinny_launch_g<TO, true, 1>(a, grid, g, s, e0, e1_main);
+        else skinny_launch_g<TO, false, 1>(a, grid, g, s, e0, e1_main);
     } else {
         const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
-        if (a.ln_colsum) klaunch(gemm_skinny_kernel<TO, true, 2, 4>, grid, dim3(SK_THREADS), 0, s, a);
-        else klaunch(gemm_skinny_kernel<TO, false, 2, 4>, grid, dim3(SK_THREADS), 0, s, a);
+        if (a.ln_colsum) klaunch_events(gemm_skinny_kernel<TO, true, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+        else klaunch_events(gemm_skinny_kernel<TO, false, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
     }
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;
         if (blocks > 1024) blocks = 1024;
-        gemm_skinny_reduce_kernel<TO><<<dim3((unsigned)blocks), 256, 0, s>>>(a);
+        klaunch_events(gemm_skinny_reduce_kernel<TO>, dim3((unsigned)blocks), dim3(256), 0, s, (hipEvent_t) nullptr, e1, a);
     }
 }
 

@@ -40,8 +40,9 @@ def _to_device_async(t, like):
 def _masked_penalty(g2d, mask, k, lamb):
     """((||g_i|| - k)^2 over the rows where mask is set).mean() * lamb, as g2d[mask] would give it but without
     boolean indexing (nonzero = a device sync in the middle of the phase)."""
-    sq = (g2d.float() ** 2).sum(1)
-    norm = torch.where(mask, sq, torch.ones_like(sq)).sqrt()
+    # vector_norm's backward is 0 at a zero row (as the reference's gradients.norm(2, dim=1)); sqrt(sum g^2) would
+    # turn a valid all-zero gradient row into inf * 0 = NaN in the critic's gradients
+    norm = torch.linalg.vector_norm(g2d.float(), dim=1)
     pen = torch.where(mask, (norm - k) ** 2, torch.zeros_like(norm))
     return pen.sum() / mask.sum() * lamb
 
@@ -87,13 +88,21 @@ class PhaseLog(Mapping):
     each phase; a training loop that reports every N steps only pays for the steps it looks at, and the host
     starts the next phase while the GPU finishes this one."""
 
-    def __init__(self, names, values, derive=None):
-        self._names, self._dev, self._derive, self._d = list(names), torch.stack(
-            [v.detach().float() for v in values]), derive, None
+    def __init__(self, names, values, derive=None, check=None):
+        """``check``: (device bool scalar, message) -- raised as a KeyError when the log is first read."""
+        vals = [v.detach().float() for v in values]
+        self._check = None
+        if check is not None and check[0] is not None:
+            vals.append(check[0].detach().float())
+            self._check = check[1]
+        self._names, self._dev, self._derive, self._d = list(names), torch.stack(vals), derive, None
 
     def _get(self):
         if self._d is None:
-            d = dict(zip(self._names, self._dev.tolist()))
+            raw = self._dev.tolist()
+            if self._check is not None and raw.pop() != 0.0:
+                raise KeyError(self._check)
+            d = dict(zip(self._names, raw))
             if self._derive is not None:
                 d.update(self._derive(d))
             self._d, self._dev = d, None
@@ -133,6 +142,7 @@ class Trainer:
         self.mone = -torch.ones([], device=dev)
         self.pad_tensor = torch.full((1, 1, 1), cfg.pad_idx, dtype=torch.long, device=dev)
         self._label_table = None
+        self._bad_labels = None
 
     # ------------------------------------------------------------------ pieces
     def _gain(self, logits, mode):
@@ -164,10 +174,18 @@ class Trainer:
         # (the reference walks a Python list, :389-400; a .tolist() here would drain the GPU queue every phase)
         if self._label_table is None or self._label_table.device != src.device:
             self._label_table = torch.tensor(cfg.label_token_ids, dtype=torch.long, device=src.device)
-        labels = (src[0, :, 0].unsqueeze(1) == self._label_table.unsqueeze(0)).long().argmax(1)
+        hit = src[0, :, 0].unsqueeze(1) == self._label_table.unsqueeze(0)
+        labels = hit.long().argmax(1)
+        # the reference's convert_label_idx raises a KeyError for an unknown label token; here the check stays on the
+        # device (no sync in the phase) and is raised when a PhaseLog of this trainer is next read
+        self._bad_labels = (~hit.any(1)).any() if self._bad_labels is None else self._bad_labels | (~hit.any(1)).any()
         labels_list = labels            # the reference's Python list; cal_disc_loss gathers with the tensor itself
         vocab_target = torch.cat([batch.tgt[1:], self.pad_tensor.repeat(1, batch.tgt.size(1), 1)])
         return labels, labels_list, real_src, real_len, vocab_target
+
+    def _label_check(self):
+        bad, self._bad_labels = self._bad_labels, None
+        return bad, "a sentence's first token is not one of cfg.label_token_ids %r" % (self.cfg.label_token_ids,)
 
     def vocab_loss(self, log_probs, target, batch_size):
         """VocabLossFn(token_mode=False, all_tokens_aware=sent_stop_aware), onmt/train_util.py:13-32."""
@@ -287,8 +305,8 @@ class Trainer:
         self._finish((self.style_discriminator, self.text_discriminator),
                      (self.style_discriminator_optim, self.text_discriminator_optim))
         return PhaseLog(("TR_gain", "TF_gain", "T_gp", "SR_gain", "SF_gain", "S_gp"),
-                        (gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp),
-                        lambda d: dict(T_cost=d["TF_gain"] - d["TR_gain"] + d["T_gp"], T_Wgap=d["TR_gain"] - d["TF_gain"],
+                        (gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp), check=self._label_check(),
+                        derive=lambda d: dict(T_cost=d["TF_gain"] - d["TR_gain"] + d["T_gp"], T_Wgap=d["TR_gain"] - d["TF_gain"],
                                        S_cost=d["SF_gain"] - d["SR_gain"] + d["S_gp"], S_Wgap=d["SR_gain"] - d["SF_gain"]))
 
     def _generator_forward_batched(self, labels, real_src, real_len, tgt_len, eval_prefix=None):
@@ -347,7 +365,8 @@ class Trainer:
         self._arm(self.style_generator, self.model)
         total.backward()
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
-        return PhaseLog(("AT_gain", "AT_acc", "AS_gain", "T_selfstyle_vloss"), (gain_t, acc, gain_s, vl))
+        return PhaseLog(("AT_gain", "AT_acc", "AS_gain", "T_selfstyle_vloss"), (gain_t, acc, gain_s, vl),
+                        check=self._label_check())
 
     def train_wgan_step(self, batch):
         """``train_discriminator(batch)`` then ``train_generator(batch)`` -- one WGAN step -- with the same results
@@ -418,7 +437,7 @@ class Trainer:
             vals.append(vl)
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
         names = ["AT_gain", "AT_acc", "AS_gain"] + (["T_selfstyle_vloss"] if cfg.ap_gen_self_style_text else [])
-        return PhaseLog(names, vals)
+        return PhaseLog(names, vals, check=self._label_check())
 
     def _train_reconstruct_batched(self, batch):
         """train_reconstruct with its independent pieces batched (cfg.batch_generator_phase), as in
@@ -472,7 +491,7 @@ class Trainer:
         self._arm(self.style_generator, self.model)
         total.backward()
         self._finish((self.style_generator, self.model), [self.style_generator_optim, self.model_optim], clip=False)
-        return PhaseLog(names, vals)
+        return PhaseLog(names, vals, check=self._label_check())
 
     def train_reconstruct(self, batch):
         cfg = self.cfg
@@ -525,7 +544,7 @@ class Trainer:
         if cfg.use_cls_feedback or not cfg.without_stl_penalty:
             optims.insert(0, self.style_generator_optim)
         self._finish((self.style_generator, self.model), optims, clip=False)
-        return PhaseLog(names, vals)
+        return PhaseLog(names, vals, check=self._label_check())
 
     def init_launch(self, batch):
         self.style_generator.train()
@@ -543,7 +562,7 @@ class Trainer:
         self._arm(self.model)
         l_v.backward()
         self._finish((self.style_generator, self.model), (self.style_generator_optim, self.model_optim))
-        return PhaseLog(("INIT_SL", "INIT_VL"), (l_style, l_v))
+        return PhaseLog(("INIT_SL", "INIT_VL"), (l_style, l_v), check=self._label_check())
 
 
 def teacher_step_loss(classifier, batch, cfg):

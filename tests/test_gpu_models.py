@@ -418,3 +418,18 @@ def test_mixed_eval_train_sweep_with_dropout(ops):
     with torch.no_grad():
         fd = float((((run(mem + eps * direction) - run(mem - eps * direction)) * w).sum() / (2 * eps)).double())
     assert abs(fd - analytic) <= 1e-2 * max(abs(fd), 1e-3), (fd, analytic)
+
+
+def test_unknown_label_token_is_reported_when_the_log_is_read(ops, golden_phases):
+    """The reference's convert_label_idx raises KeyError for a first token outside label_tokens
+    (onmt/train_and_translate.py:60-61); here the lookup stays on the device and the error surfaces with the log."""
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    cfg = MSSRConfig.small()
+    tr = Trainer(make_nets(golden_phases, cfg), cfg)
+    b = gpu_batch(golden_phases)
+    b.src = b.src.clone()
+    b.src[0, 1, 0] = 9                        # a word where the style label token belongs
+    log = tr.init_launch(b)
+    with pytest.raises(KeyError, match="label_token_ids"):
+        log["INIT_SL"]
+    assert tr.init_launch(gpu_batch(golden_phases))["INIT_SL"] > 0       # the flag does not stick
