@@ -1,0 +1,92 @@
+#!/usr/bin/env python
+"""profiles/rNN_pmc_fetch_size.csv + rNN_pmc_write_size.csv  ->  profiles/rNN_pmc_traffic.json
+
+The two inputs are the per-kernel summaries tools/pmc.sh writes from two separate `rocprofv3 --pmc` passes of
+`python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline [--workload W]` (FETCH_SIZE and WRITE_SIZE do
+not fit one pass: 3 + 2 of the 4 TCC counters).  Both counters are in KiB.  On gfx950 FETCH_SIZE tallies a 128-byte
+request as 64 bytes, so MI355X_MICROARCH.md prescribes doubling it before comparing with a byte count:
+
+    traffic_bytes_per_launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 / dispatches
+
+bench.py's kernel names (ops.stop_profile) group the instantiations rocprofv3 lists separately (the G template
+parameter = rows per block is not part of the bench name); the groups are summed dispatch-weighted.
+
+    python tools/pmc_traffic.py wgan profiles/r02_pmc_fetch_size.csv profiles/r02_pmc_write_size.csv profiles/r02_pmc_traffic.json
+"""
+import csv
+import json
+import os
+import re
+import sys
+
+RULES = [
+    # rocprofv3 leaves names with a __hip_bfloat16 template argument mangled (DF16b); the LN = true instantiation is
+    # demangled, wrongly, as "<bool _Accum, bool, E, F, G>"
+    (re.compile(r"gemm_skinny_kernelIDF16bLb0ELi(\d+)ELi\d+E"), "gemm_skinny_kernel<bf16,noLN,%s>"),
+    (re.compile(r"gemm_skinny_kernelIDF16bLb1ELi(\d+)ELi\d+E"), "gemm_skinny_kernel<bf16,LN,%s>"),
+    (re.compile(r"gemm_skinny_kernel<bool _Accum, bool, E, (\d+), \d+>"), "gemm_skinny_kernel<bf16,LN,%s>"),
+    (re.compile(r"gemm_skinny_kernel<float, false, (\d+), \d+>"), "gemm_skinny_kernel<f32,noLN,%s>"),
+    (re.compile(r"gemm_lnb_kernelIDF16bE"), "gemm_lnb_kernel<bf16>"),
+    (re.compile(r"gemm_lnb_kernel<float>"), "gemm_lnb_kernel<f32>"),
+    (re.compile(r"gemm_tn_kernel<float, \d+>"), "gemm_tn_kernel<f32>"),
+    (re.compile(r"gemm_tn_kernelIDF16bLi\d+E"), "gemm_tn_kernel<bf16>"),
+    (re.compile(r"gemm_kernelIDF16bDF16bLi(\d+)ELi\d+E"), "gemm_kernel<bf16,bf16,%s>"),
+    (re.compile(r"gemm_kernelIDF16bfLi(\d+)ELi\d+E"), "gemm_kernel<bf16,f32,%s>"),
+    (re.compile(r"gemm_kernel<float, float, (\d+), \d+>"), "gemm_kernel<f32,f32,%s>"),
+]
+
+
+def bench_name(kernel):
+    for rx, fmt in RULES:
+        m = rx.search(kernel)
+        if m:
+            return fmt % m.groups() if m.groups() else fmt
+    return None
+
+
+def read(path, counter):
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["counter"] != counter:
+                continue
+            name = bench_name(r["kernel"])
+            if name is None:
+                continue
+            n, tot = out.get(name, (0, 0.0))
+            out[name] = (n + int(r["dispatches"]), tot + float(r["total"]))
+    return out
+
+
+def main():
+    workload, fetch_csv, write_csv, out_json = sys.argv[1:5]
+    fetch, write = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
+    kernels = {}
+    for name, (n, f_kib) in sorted(fetch.items()):
+        wn, w_kib = write.get(name, (0, 0.0))
+        if wn != n:
+            print("skip %s: %d dispatches in the fetch pass, %d in the write pass" % (name, n, wn))
+            continue
+        kernels[name] = dict(
+            dispatches=n,
+            fetch_size_raw_kib_per_launch=round(f_kib / n, 2),
+            fetch_bytes_per_launch_gfx950_corrected=int(2 * f_kib * 1024 / n),
+            write_bytes_per_launch=int(w_kib * 1024 / n),
+            traffic_bytes_per_launch=int((2 * f_kib + w_kib) * 1024 / n))
+    doc = {}
+    if os.path.exists(out_json):
+        with open(out_json) as f:
+            doc = json.load(f)
+    doc.setdefault("note", "HBM bytes per launch = (2 x FETCH_SIZE + WRITE_SIZE) KiB, two separate rocprofv3 --pmc passes "
+                           "(tools/pmc.sh), gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md applied; grouped by "
+                           "bench.py kernel name (tools/pmc_traffic.py)")
+    doc.setdefault("workloads", {})[workload] = kernels
+    doc.setdefault("sources", {})[workload] = [os.path.basename(fetch_csv), os.path.basename(write_csv)]
+    with open(out_json, "w") as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    for k, v in kernels.items():
+        print("%-44s %6d launches  %9d B traffic" % (k, v["dispatches"], v["traffic_bytes_per_launch"]))
+
+
+if __name__ == "__main__":
+    main()
