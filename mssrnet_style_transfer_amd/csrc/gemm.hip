@@ -277,7 +277,11 @@ static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
     gemm_fill_args(d, a);
     hipStream_t s = (hipStream_t)stream;
     const int pi = prof_begin(s);
-    if (d->k_seg_len > 0) {         // only the weight-gradient kernel walks a segmented k
+    if (d->k_seg_len > 0) {         // only the weight-gradient kernels walk a segmented k
+        if (!d->no_skinny && gemm_pipe_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+            prof_end(pi, s, 4, d->in_dtype, d->out_dtype, 128, batch, d->m, d->n, d->k);
+            MSSR_LAUNCH_OK("gemm(pipe)");
+        }
         if (!d->no_skinny && gemm_tn_try(a, d->in_dtype, d->out_dtype, batch, s)) {
             prof_end(pi, s, 2, d->in_dtype, d->out_dtype, 64, batch, d->m, d->n, d->k);
             MSSR_LAUNCH_OK("gemm(tn)");
@@ -285,10 +289,23 @@ static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
         set_error("%s: a segmented k needs the weight-gradient form (bf16, A m-contiguous, B n-contiguous, plain epilogue)", who);
         return MSSR_ERR_UNSUPPORTED;
     }
+    // measured (scratch/pipe_bench.py): from this many rows on the LDS-tiled DMA kernel beats the K-split one
+    static const int64_t pipe_first_min_m = [] {
+        const char* e = getenv("MSSR_PIPE_FIRST_MINM");
+        return e ? (int64_t)atoll(e) : (int64_t)2048;
+    }();
+    if (!d->no_skinny && d->m >= pipe_first_min_m && gemm_pipe_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+        prof_end(pi, s, 4, d->in_dtype, d->out_dtype, 128, batch, d->m, d->n, d->k);
+        MSSR_LAUNCH_OK("gemm(pipe)");
+    }
     if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {
         prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_tile(d->m, d->n, d->k), batch, d->m, d->n, d->k,
                  gemm_skinny_ksplit(d->k), d->ln_colsum ? 1 : 0);
         MSSR_LAUNCH_OK("gemm(skinny)");
+    }
+    if (!d->no_skinny && gemm_pipe_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+        prof_end(pi, s, 4, d->in_dtype, d->out_dtype, 128, batch, d->m, d->n, d->k);
+        MSSR_LAUNCH_OK("gemm(pipe)");
     }
     if (!d->no_skinny && gemm_tn_try(a, d->in_dtype, d->out_dtype, batch, s)) {
         prof_end(pi, s, 2, d->in_dtype, d->out_dtype, 64, batch, d->m, d->n, d->k);

@@ -592,7 +592,8 @@ def test_gemm_tn_weight_gradient_kernel(ops, M, N, K, batch):
     ops.start_profile()
     out = ops.gemm(dy.transpose(1, 2), x, False, torch.float32)
     rec = ops.stop_profile()
-    assert rec[0]["kernel"].startswith("gemm_tn_kernel"), rec[0]["kernel"]
+    # large aligned problems go to the LDS-DMA kernel (gemm_pipe.hip), the rest to the register-staged one (gemm_tn.hip)
+    assert rec[0]["kernel"].startswith(("gemm_tn_kernel", "gemm_pipe_kernel")), rec[0]["kernel"]
     assert_close(out, ref, 2e-5 * math.sqrt(K), "tn f32")
     out16 = ops.gemm(dy.transpose(1, 2), x, False, torch.bfloat16)
     assert_close(out16.float(), ref, 1e-2, "tn bf16")
@@ -608,6 +609,57 @@ def test_gemm_tn_weight_gradient_kernel(ops, M, N, K, batch):
         dys, xs = dy[0][:, 3:M - 2], x[0][:, 1:N - 4]
         o = ops.gemm(dys.t(), xs, False, torch.float32)
         assert_close(o, ref[0][3:M - 2, 1:N - 4], 2e-5 * math.sqrt(K), "tn sliced")
+
+
+PIPE_CASES = [
+    # form, batch dims, M, N, K      (nt: b is [N,K]; nn: b is [K,N]; tn: a is a transposed view of [K,M], b is [K,N])
+    ("nt", (), 8192, 512, 512), ("nt", (), 8200, 520, 544), ("nn", (), 8192, 512, 512), ("nn", (), 4100, 264, 96),
+    ("nt", (3,), 2048, 384, 64), ("nn", (2, 2), 1024, 256, 128), ("tn", (), 512, 512, 2240), ("tn", (12,), 512, 256, 1440),
+    ("tn", (), 1536, 512, 35840), ("tn", (), 9608, 512, 2240), ("nt", (), 32768, 512, 1024),
+]
+
+
+@pytest.mark.parametrize("form,bd,M,N,K", PIPE_CASES)
+def test_gemm_pipe_kernel(ops, form, bd, M, N, K):
+    """The LDS-DMA 128x128 kernel (gemm_pipe.hip) in its three operand forms against fp64: plain, fp32 output, ragged
+    edges (M, N not multiples of 128, K % 64 == 32), batched, K sliced with atomics; and its vectorised epilogue
+    (bias, ReLU, dropout, residual, gate, alpha / beta) against the register-staged kernel of gemm.hip run on the same
+    operands and the same dropout seed (no_skinny=True forces that kernel): same masks, same values up to bf16 rounding."""
+    torch.manual_seed(M + 3 * N + K)
+    if form == "tn":
+        at = torch.randn(*bd, K, M).bfloat16().cuda()
+        a = at.transpose(-1, -2)
+    else:
+        a = torch.randn(*bd, M, K).bfloat16().cuda()
+    tb = form == "nt"
+    b = (torch.randn(*bd, N, K) if tb else torch.randn(*bd, K, N)).bfloat16().cuda()
+    ref = a.double() @ (b.double().transpose(-1, -2) if tb else b.double())
+    ops.start_profile()
+    out = ops.gemm(a, b, tb, torch.float32)
+    rec = ops.stop_profile()
+    assert rec[0]["kernel"].startswith("gemm_pipe_kernel"), rec[0]["kernel"]
+    assert_close(out, ref, 2e-5 * math.sqrt(K), "pipe %s f32" % form)
+    out16 = ops.gemm(a, b, tb, torch.bfloat16)
+    assert_close(out16.float(), ref, 1e-2, "pipe %s bf16" % form)
+    acc = torch.randn(*bd, M, N, device="cuda")
+    want = acc.double() + 2.0 * ref
+    ops.gemm(a, b, tb, torch.float32, out=acc, alpha=2.0, beta=1.0)
+    assert_close(acc, want, 3e-5 * math.sqrt(K), "pipe %s accumulate" % form)
+    if form == "tn":
+        return
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(*bd, M, N, device="cuda").bfloat16()
+    gate = torch.randn(*bd, M, N, device="cuda").bfloat16()
+    for od in (torch.bfloat16, torch.float32):
+        kw = dict(bias=bias, relu=True, residual=res, gate=gate, alpha=0.5, drop_p=0.25, drop_seed=1234)
+        got = ops.gemm(a, b, tb, od, **kw)
+        old = ops.gemm(a, b, tb, od, no_skinny=True, **kw)
+        assert_close(got.float(), old.float(), 1e-2 if od == torch.bfloat16 else 1e-5, "pipe %s epilogue %s" % (form, od))
+        assert bool(((got == 0) == (old == 0)).all()), "dropout / gate masks differ"
+        c0 = torch.randn(*bd, M, N, device="cuda").to(od)
+        got = ops.gemm(a, b, tb, od, bias=bias, out=c0.clone(), beta=0.5)
+        assert_close(got.float(), ref + bias.double() + 0.5 * c0.double(), 1e-2 if od == torch.bfloat16 else 3e-5 * math.sqrt(K),
+                     "pipe %s beta %s" % (form, od))
 
 
 def test_adam_and_global_norm_clip_match_torch():
