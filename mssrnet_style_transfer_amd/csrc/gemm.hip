@@ -105,7 +105,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+    // p.ksplit > 1: blockIdx.z = batch * ksplit + K slice; the slices add into the pre-set fp32 output with atomics
+    const int64_t zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
+    const int64_t zo = zb / p.batch_inner, zi = zb % p.batch_inner;
     const TI* A = reinterpret_cast<const TI*>(p.a) + zo * p.a_bo + zi * p.a_bi;
     const TI* B = reinterpret_cast<const TI*>(p.b) + zo * p.b_bo + zi * p.b_bi;
     const int64_t coff = zo * p.c_bo + zi * p.c_bi;
@@ -120,10 +122,12 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
 
     TileLoader<TI, BM> la;
     TileLoader<TI, BN> lb;
-    const int64_t nk = (p.k + BK - 1) / BK;
-    la.fetch(A, m0, 0, p.m, p.k, p.a_rs, p.a_cs, a_km, p.a_vec);
-    lb.fetch(B, n0, 0, p.n, p.k, p.b_cs, p.b_rs, b_km, p.b_vec);   // rows of the B image are n
-    for (int64_t t = 0; t < nk; ++t) {
+    const int64_t nk_all = (p.k + BK - 1) / BK;
+    const int64_t per = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int64_t t0 = zs * per, nk = t0 + per < nk_all ? t0 + per : nk_all;
+    la.fetch(A, m0, t0 * BK, p.m, p.k, p.a_rs, p.a_cs, a_km, p.a_vec);
+    lb.fetch(B, n0, t0 * BK, p.n, p.k, p.b_cs, p.b_rs, b_km, p.b_vec);   // rows of the B image are n
+    for (int64_t t = t0; t < nk; ++t) {
         la.commit(As, a_km);
         lb.commit(Bs, b_km);
         __syncthreads();
@@ -161,6 +165,10 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 4; ++r) {
                 const int64_t row = m0 + wm * WM + i * 16 + (lane >> 4) * 4 + r;
                 if (row >= p.m) continue;
+                if (p.ksplit > 1) {
+                    if constexpr (sizeof(TO) == 4) atomicAdd(reinterpret_cast<float*>(C) + row * p.ldc + col, p.alpha * acc[i][j][r]);
+                    continue;
+                }
                 epilogue_store<TI, TO>(p, acc[i][j][r], row, col, bias, C, R, G, (int64_t)blockIdx.z * p.m * p.n);
             }
         }
@@ -186,9 +194,30 @@ static inline int pick_tile(int64_t m, int64_t n, int64_t batch) {
     return use_tile64(m, n, batch) ? 6464 : 3232;
 }
 
+// K slices for the general kernel: few output tiles and a long reduction with a plain fp32 output (the critics' score
+// layers: dW of a Linear(d -> 1) is a 1 x d x rows product, one block looping over 32 768 rows took 0.9-1.5 ms)
+static int general_ksplit(const GemmArgs& a, int64_t batch, int out_dtype, int tile) {
+    if (out_dtype != MSSR_F32 || a.k < 2048) return 1;
+    if (a.bias || a.residual || a.gate || a.relu || a.drop_p > 0.f || (a.beta != 0.f && a.beta != 1.f)) return 1;
+    if (a.ldc != a.n || !(batch == 1 || (a.c_bi == a.m * a.n && a.batch_inner == batch))) return 1;
+    const int bm = tile == 3232 ? 32 : tile == 6464 ? 64 : 128, bn = tile == 3232 ? 32 : tile == 6464 ? 64 : 128;
+    const int64_t blocks = ((a.m + bm - 1) / bm) * ((a.n + bn - 1) / bn) * batch;
+    if (blocks >= 256) return 1;
+    int64_t ks = (512 + blocks - 1) / blocks;
+    if (ks > a.k / 512) ks = a.k / 512;
+    if (ks > 128) ks = 128;
+    if (ks * batch > 65535) ks = 65535 / batch;
+    return ks > 1 ? (int)ks : 1;
+}
+
 template <typename TI, typename TO>
-static void launch(const GemmArgs& a, int64_t batch, hipStream_t s) {
-    const int t = pick_tile(a.m, a.n, batch);
+static void launch(const GemmArgs& a0, int64_t batch0, hipStream_t s) {
+    const int t = pick_tile(a0.m, a0.n, batch0);
+    GemmArgs a = a0;
+    a.ksplit = general_ksplit(a0, batch0, sizeof(TO) == 4 ? MSSR_F32 : MSSR_BF16, t);
+    if (a.ksplit > 1 && a.beta == 0.f &&
+        hipMemsetAsync(a.c, 0, sizeof(float) * (size_t)(a.m * a.n * batch0), s) != hipSuccess) a.ksplit = 1;
+    const int64_t batch = batch0 * a.ksplit;
     // MSSR_GEMM_LOG=1: one stderr line per launch of this (general) kernel -- which problems miss the K-split kernel
     static const bool log_shapes = getenv("MSSR_GEMM_LOG") != nullptr;
     if (log_shapes)

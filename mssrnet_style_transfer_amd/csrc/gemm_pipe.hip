@@ -140,9 +140,11 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // RM operands are fetched in 8-column chunks: a ragged width reads on into the row's padding (ld >= width rounded up)
+    const int64_t a_ext = A_KM ? p.m : (p.m + 7) & ~(int64_t)7, b_ext = B_KM ? p.n : (p.n + 7) & ~(int64_t)7;
     if (t_begin < t_end) {
-        pp_stage<A_KM>(A, P.a_ld, m0, p.m, t_begin * PP_BK, p.k, smem, P.seg_len, P.seg_stride);
-        pp_stage<B_KM>(B, P.b_ld, n0, p.n, t_begin * PP_BK, p.k, smem + PP_TILE_BYTES, P.seg_len, P.seg_stride);
+        pp_stage<A_KM>(A, P.a_ld, m0, a_ext, t_begin * PP_BK, p.k, smem, P.seg_len, P.seg_stride);
+        pp_stage<B_KM>(B, P.b_ld, n0, b_ext, t_begin * PP_BK, p.k, smem + PP_TILE_BYTES, P.seg_len, P.seg_stride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -152,8 +154,8 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
         const unsigned char* Bt = At + PP_TILE_BYTES;
         if (t + 1 < t_end) {
             unsigned char* An = smem + (cur ^ 1) * 2 * PP_TILE_BYTES;
-            pp_stage<A_KM>(A, P.a_ld, m0, p.m, (t + 1) * PP_BK, p.k, An, P.seg_len, P.seg_stride);
-            pp_stage<B_KM>(B, P.b_ld, n0, p.n, (t + 1) * PP_BK, p.k, An + PP_TILE_BYTES, P.seg_len, P.seg_stride);
+            pp_stage<A_KM>(A, P.a_ld, m0, a_ext, (t + 1) * PP_BK, p.k, An, P.seg_len, P.seg_stride);
+            pp_stage<B_KM>(B, P.b_ld, n0, b_ext, (t + 1) * PP_BK, p.k, An + PP_TILE_BYTES, P.seg_len, P.seg_stride);
         }
         const int ksteps = (p.k - t * PP_BK) >= PP_BK ? 2 : 1;
 #pragma unroll
@@ -310,8 +312,9 @@ bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch
     if (!b_km && g.b_cs != 1) return false;
     if (a_ld % 8 || b_ld % 8 || a_ld < 8 || b_ld < 8 || !aligned(g.a, 16) || !aligned(g.b, 16)) return false;
     if (g.a_bo % 8 || g.a_bi % 8 || g.b_bo % 8 || g.b_bi % 8) return false;
-    if (!a_km && g.m % 8) return false;                      // RM operands are fetched in 8-column chunks
-    if (!b_km && g.n % 8) return false;
+    // RM operands are fetched in 8-column chunks: a ragged width needs rows padded to the next multiple of 8
+    if (!a_km && a_ld < ((g.m + 7) & ~(int64_t)7)) return false;
+    if (!b_km && b_ld < ((g.n + 7) & ~(int64_t)7)) return false;
     if (g.k_seg_len > 0 && (a_km || g.k_seg_len < 1 || g.k >= (int64_t)1 << 31 || g.k_seg_stride >= (int64_t)1 << 31)) return false;
     if (!a_km && (g.bias || g.residual || g.gate || g.relu || g.drop_p > 0.f)) return false;
     const int64_t tm = (g.m + PP_BM - 1) / PP_BM, tn = (g.n + PP_BN - 1) / PP_BN;

@@ -662,6 +662,40 @@ def test_gemm_pipe_kernel(ops, form, bd, M, N, K):
                      "pipe %s beta %s" % (form, od))
 
 
+@pytest.mark.parametrize("M,N,K,dtype", [(1, 512, 32768, torch.float32), (1, 129, 33280, torch.bfloat16),
+                                         (512, 256, 8192, torch.float32), (4, 256, 4100, torch.bfloat16)])
+def test_gemm_general_kernel_k_slices(ops, M, N, K, dtype):
+    """Few output tiles, long reduction, fp32 output (weight gradients of the critics' score layers): the general
+    kernel slices K over blockIdx.z and adds the slices with atomics; beta = 0 and beta = 1."""
+    torch.manual_seed(K + N)
+    at = torch.randn(K, M).to(dtype).cuda()
+    b = torch.randn(K, N).to(dtype).cuda()
+    ref = at.double().t() @ b.double()
+    out = ops.gemm(at.t(), b, False, torch.float32, no_skinny=True)
+    tol = 2e-5 * math.sqrt(K)
+    assert_close(out, ref, tol, "k-sliced general kernel")
+    acc = torch.randn(M, N, device="cuda")
+    want = acc.double() + ref
+    ops.gemm(at.t(), b, False, torch.float32, out=acc, beta=1.0, no_skinny=True)
+    assert_close(acc, want, tol, "k-sliced general kernel, beta = 1")
+
+
+def test_gemm_pipe_ragged_width_of_a_padded_operand(ops):
+    """dW = dlogits^T x with V = 9606 columns stored in rows padded to 9632 (the vocabulary slabs of the decode engine):
+    the 8-column chunks of the last tile read on into the padding, whose garbage only reaches rows that are not stored."""
+    torch.manual_seed(1)
+    K, V, Vp, N = 2240, 9606, 9632, 512
+    buf = torch.full((K, Vp), float("nan")).bfloat16().cuda()
+    buf[:, :V] = torch.randn(K, V).bfloat16().cuda()
+    x = torch.randn(K, N).bfloat16().cuda()
+    dl = buf[:, :V]
+    ops.start_profile()
+    out = ops.gemm(dl.t(), x, False, torch.float32)
+    rec = ops.stop_profile()
+    assert rec[0]["kernel"].startswith("gemm_pipe_kernel"), rec[0]["kernel"]
+    assert_close(out, dl.double().t() @ x.double(), 2e-5 * math.sqrt(K), "ragged RM operand")
+
+
 def test_adam_and_global_norm_clip_match_torch():
     """csrc/optim.hip against torch.nn.utils.clip_grad_norm_ + torch.optim.Adam (what onmt/trainer_wgan_wh.py:192-211,
     623-628 runs): odd sizes, a parameter without gradient, clipping active and inactive, five steps."""
