@@ -11,7 +11,8 @@ semantics -- reduced grad = (sum over ranks) / world -- once per optimizer step:
   is gathered into its flat buffer (one multi-tensor copy) and its all-reduce launched on a side
   stream, overlapping the rest of that backward;
 * ``__call__(modules)`` after the last backward: reduces whatever was not armed / not
-  flushed, waits for the side stream, divides by world and scatters back into ``.grad``.
+  flushed, waits for the side stream, divides by world and points every ``.grad`` at its slice of the
+  reduced flat buffer (no scatter copy: the optimizer reads the slices in place).
 
 One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets default to 32 MiB so that each
@@ -105,12 +106,16 @@ class GradSync:
     def _fill(self, b):
         """Gradients of the bucket's parameters -> its flat buffer: ONE multi-tensor copy (two kernels per
         bucket instead of two per parameter); parameters without a gradient contribute zeros."""
-        dst = [v for v, p in zip(b["views"], b["params"]) if p.grad is not None]
-        src = [p.grad for p in b["params"] if p.grad is not None]
-        if len(dst) < len(b["params"]):
+        live = [(v, p.grad) for v, p in zip(b["views"], b["params"]) if p.grad is not None]
+        if len(live) < len(b["params"]):
+            # (a gradient that still IS its slice -- accumulation without zero_grad -- must survive the zero fill)
+            keep = [(v, g.clone()) for v, g in live if g.data_ptr() == v.data_ptr()]
             b["flat"].zero_()
-        if dst:
-            torch._foreach_copy_(dst, src)
+            live = [(v, g) for v, g in live if g.data_ptr() != v.data_ptr()] + keep
+        else:
+            live = [(v, g) for v, g in live if g.data_ptr() != v.data_ptr()]
+        if live:
+            torch._foreach_copy_([v for v, _ in live], [g for _, g in live])
 
     def _launch(self, b):
         if not self.active:
@@ -178,11 +183,15 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self._stream)
         inv = 1.0 / self.world
         for b, _ in self._pending:
-            b["flat"].mul_(inv)
+            if self.world > 1:
+                b["flat"].mul_(inv)
+            # No scatter back: every parameter's .grad BECOMES its slice of the reduced flat buffer (a pointer swap
+            # on the host; the optimizer reads the slices in place).  The slices stay valid until this bucket is
+            # filled again, i.e. until the next backward of these parameters has finished -- by then zero_grad() has
+            # dropped them (or, if the caller accumulates without zero_grad, autograd has added into them in place and
+            # _fill's copy is a copy onto itself).
             for v, p in zip(b["views"], b["params"]):
-                if p.grad is None:
-                    p.grad = v.clone().to(p.dtype)
-            torch._foreach_copy_([p.grad for p in b["params"]], b["views"])
+                p.grad = v
             b["ready"], b["launched"] = 0, False
         self._pending = []
 
