@@ -399,8 +399,8 @@ typedef struct {
     void* d_e;                    /* [T][B, d] gradient of the soft-embedding product */
     void* dnf;                    /* [T][B, d] */
     /* greedy search (beam 1): onmt/translate/translator_wh.py:709-746 + onmt/translate/greedy_search.py:135-165.
-     * greedy = 1 (forward-only plans): the next step's input is the one-hot of the argmax token instead of
-     * the probabilities, and the token goes to ids[step][b] (int32).  Sentences are independent, so running
+     * greedy = 1 (forward-only plans): each step writes only the argmax token ids[step][b] (int32; no probability
+     * slab), and steps > 0 embed ids[step-1] by a lookup in `emb` (step 0 reads the one-hot <s> of in_all[0]).  Sentences are independent, so running
      * finished ones on (instead of compacting the batch as the reference does) leaves the others unchanged. */
     int32_t* ids;                 /* [T][B] or NULL */
     int greedy;

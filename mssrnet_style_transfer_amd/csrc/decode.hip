@@ -640,6 +640,58 @@ __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict
     }
 }
 
+// Greedy search, steps > 0: the input is a token id, so its embedding is a row of the table, not a one-hot product
+// (onmt/modules/embeddings.py:282 lookup path): x0[r,:] = E[ids[r],:] * s + pe[step]  (eval mode: no dropout).
+// Bit-identical to the one-hot GEMM it replaces: that product is the table row in the compute dtype.
+template <typename T>
+__global__ __launch_bounds__(256) void embed_lookup_kernel(const T* __restrict__ emb, const int* __restrict__ ids,
+                                                           const float* __restrict__ pe, T* __restrict__ out, int rows,
+                                                           int d, int V, int step, float s) {
+    const int64_t n = (int64_t)rows * d;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+        const int r = (int)(i / d), c = (int)(i % d);
+        int id = ids[r];
+        id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+        float v[4], pp[4], o[4];
+        V4<T>::load(emb + (int64_t)id * d + c, v);
+        V4<float>::load(pe + (int64_t)step * d + c, pp);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = v[j] * s + pp[j];
+        V4<T>::store(out + i, o);
+    }
+}
+
+// Greedy search: ids[row] = argmax of the row's logits (lowest index on ties, as torch.topk(1) / argmax;
+// onmt/translate/greedy_search.py:135-165 with beam 1).  softmax is monotone, so no probabilities are formed.
+template <typename T>
+__global__ __launch_bounds__(256) void vocab_argmax_kernel(const T* __restrict__ logits, int64_t ldl, int n,
+                                                           int* __restrict__ ids) {
+    __shared__ float sm[4];
+    __shared__ int si[4];
+    const int t = threadIdx.x, row = blockIdx.x;
+    float mx = -INFINITY;
+    int mi = 0x7fffffff;
+    for (int c = t; c < n; c += 256) {
+        const float v = to_f(logits[(int64_t)row * ldl + c]);
+        if (v > mx) { mx = v; mi = c; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float om = __shfl_xor(mx, o, 64);
+        const int oi = __shfl_xor(mi, o, 64);
+        if (om > mx || (om == mx && oi < mi)) { mx = om; mi = oi; }
+    }
+    if ((t & 63) == 0) { sm[t >> 6] = mx; si[t >> 6] = mi; }
+    __syncthreads();
+    if (t == 0) {
+        mx = sm[0]; mi = si[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (sm[w] > mx || (sm[w] == mx && si[w] < mi)) { mx = sm[w]; mi = si[w]; }
+        ids[row] = mi == 0x7fffffff ? 0 : mi;
+    }
+}
+
 // probs = softmax(logits * inv_t): fp32 result (the user-visible [B,V] slab) + a copy in the
 // compute dtype into the next step's padded GEMM operand row.  One 256-thread block per row.
 // greedy: the next input is the one-hot of the row's argmax instead (lowest index on ties, as
@@ -902,6 +954,16 @@ static int step_fwd(const Ctx& c, int step) {
     int rc;
     // embedding of the (soft) input: e = in[step] . E ; x0 = dropout(e*sqrt(d) + pe[step])
     const void* in = G.rows(p->in_all, step, p->Vp);
+    if (p->greedy && step > 0) {        // the input is last step's token: a row of the table
+        const unsigned g = (unsigned)((Rd / 4 + 255) / 256);
+        const int* prev = p->ids + (int64_t)(step - 1) * B + G.r0;
+        if (c.dt == MSSR_F32)
+            embed_lookup_kernel<float><<<g, 256, 0, c.s>>>((const float*)p->emb, prev, p->pe, (float*)G.X(0), R, d, p->V,
+                                                           step, sqrtf((float)d));
+        else
+            embed_lookup_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)p->emb, prev, p->pe, (bf16*)G.X(0), R, d, p->V, step,
+                                                          sqrtf((float)d));
+    } else {
     if ((rc = gemm_nt(c, in, p->Vp, p->emb_t, p->Vp, G.tmp(), d, R, d, p->Vp, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                       0.f, c.dt, 0.f, 0)))
         return rc;
@@ -913,6 +975,7 @@ static int step_fwd(const Ctx& c, int step) {
         else
             embed_epilogue_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)G.tmp(), p->pe, (bf16*)G.X(0), R, d, step,
                                                             sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows);
+    }
     }
     for (int l = 0; l < NL; ++l) {
         const mssr_dec_layer& L = p->layers[l];
@@ -990,6 +1053,12 @@ static int step_fwd(const Ctx& c, int step) {
         if ((rc = gemm_nt(c, nf, d, p->w_gen, d, G.logits(), p->Vp, R, p->V, d, p->b_gen, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))
             return rc;
+    }
+    if (p->greedy) {                    // the token is all the next step needs (embed_lookup_kernel)
+        int* out_ids = p->ids + (int64_t)step * B + G.r0;
+        if (c.dt == MSSR_F32) vocab_argmax_kernel<float><<<R, 256, 0, c.s>>>((const float*)G.logits(), p->Vp, p->V, out_ids);
+        else vocab_argmax_kernel<bf16><<<R, 256, 0, c.s>>>((const bf16*)G.logits(), p->Vp, p->V, out_ids);
+        MSSR_LAUNCH_OK("decode_step_fwd");
     }
     float* probs = p->probs + ((int64_t)step * B + G.r0) * p->V;
     void* copy = G.rows(p->in_all, step + 1, p->Vp);                        // in_all has T+1 slots

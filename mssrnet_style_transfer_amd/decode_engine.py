@@ -217,8 +217,9 @@ def _colsum(x):
     return out
 
 
-def _make_plan(spec, mem):
-    """Slabs + mssr_decode_plan for one decode over ``mem`` [B, Ls, d] (forward part)."""
+def _make_plan(spec, mem, greedy=False):
+    """Slabs + mssr_decode_plan for one decode over ``mem`` [B, Ls, d] (forward part).  ``greedy``: a forward-only
+    plan that hands token ids from step to step -- no probability slab, one input slot (the one-hot <s>)."""
     pk = spec.pack
     cd, dev = pk.cd, mem.device
     B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
@@ -230,8 +231,8 @@ def _make_plan(spec, mem):
     e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
     bufs = dict(
         mem=memc, mem_kv=mem_kv,
-        in_all=torch.zeros(T + 1, B, Vp, dtype=cd, device=dev),
-        probs=e(T, B, V, dtype=torch.float32),
+        in_all=torch.zeros(1 if greedy else T + 1, B, Vp, dtype=cd, device=dev),
+        probs=e(1 if greedy else T, 1 if greedy else B, V, dtype=torch.float32),
         X=e(NL + 1, Ts * B, d), qkv=e(NL, T * B, 3 * d), actD=e(NL, 8, Ts * B, d), actF=e(NL, Ts * B, ff),
         stats=e(3 * NL + 1, 2, Ts * B, dtype=torch.float32), nf=e(Ts * B, d), logits=e(B, Vp), tmp=e(B, d),
         ws=ops._workspace(dev))
@@ -424,28 +425,59 @@ def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0):
     return _SoftDecode.apply(spec, mem, *params)
 
 
-def greedy_decode_ids(model, cfg, memory_bank, src_lengths, max_length, check_every=4):
+def greedy_decode_ids(model, cfg, memory_bank, src_lengths, max_length, check_every=4, compact_below=0.75):
     """Greedy search with beam 1 on the decode engine: token ids [steps, B] (int32; steps <= max_length,
     the loop stops once every sentence has produced </s>) -- the step loop of
     onmt/translate/translator_wh.py:709-746 with GreedySearch.advance (greedy_search.py:135-165).
-    The reference drops finished sentences from the batch (update_finished + map_state(index_select),
-    translator_wh.py:744-746); sentences are independent, so here they simply run on and the caller
-    cuts each one at its first </s>."""
+
+    Finished sentences leave the batch as in the reference (update_finished + map_state(index_select),
+    translator_wh.py:744-746, decoders/transformer.py:274-287), but only at the host's check points (every
+    ``check_every`` steps, where the loop reads the done flags anyway) and only once fewer than ``compact_below``
+    of the current rows are still running: the survivors' memory bank, self-attention cache rows and last tokens are
+    gathered into a smaller plan and the sweep continues on it.  What a row holds after its sentence's first </s> is
+    unspecified (tokens of the steps it kept running, then </s>); the caller cuts each sentence at its first </s>."""
     lib = L.load()
     params = decoder_params(model)
+    dev = memory_bank.device
     with torch.no_grad():
         spec = _make_spec(model, cfg, memory_bank, src_lengths, max_length, params)
         spec.training, spec.save, spec.temperature, spec.eval_rows = False, False, 1.0, 0
-        plan, bufs = _make_plan(spec, memory_bank.transpose(0, 1).contiguous())
-        ids = torch.zeros(spec.T, spec.B, dtype=torch.int32, device=memory_bank.device)
-        plan.ids, plan.greedy = ids.data_ptr(), 1
-        done = torch.zeros(spec.B, dtype=torch.bool, device=memory_bank.device)
-        steps = 0
-        for step in range(spec.T):
+        T, B0 = spec.T, spec.B
+        out = torch.full((T, B0), cfg.eos_idx, dtype=torch.int32, device=dev)
+        rows = torch.arange(B0, device=dev)               # original sentence of every row of the current plan
+        mem_cur, len_cur = memory_bank, src_lengths
+
+        def new_plan(sp, mem):
+            plan, bufs = _make_plan(sp, mem.transpose(0, 1).contiguous(), greedy=True)
+            ids = torch.zeros(sp.T, sp.B, dtype=torch.int32, device=dev)
+            plan.ids, plan.greedy = ids.data_ptr(), 1
+            return plan, bufs, ids
+
+        plan, bufs, ids = new_plan(spec, mem_cur)
+        done = torch.zeros(B0, dtype=torch.bool, device=dev)
+        steps = flushed = 0
+        for step in range(T):
             L.check(lib.mssr_decode_step_fwd(ctypes.byref(plan), step, L.stream()), "decode_step_fwd")
             steps = step + 1
-            if steps % check_every == 0 or steps == spec.T:
-                done |= (ids[steps - check_every if steps >= check_every else 0:steps] == cfg.eos_idx).any(0)
-                if bool(done.all()):                      # one host sync every `check_every` steps
-                    break
-    return ids[:steps]
+            if steps % check_every and steps != T:
+                continue
+            out[flushed:steps, rows] = ids[flushed:steps]
+            done[rows] |= (ids[flushed:steps] == cfg.eos_idx).any(0)
+            flushed = steps
+            live = ~done[rows]
+            n_live = int(live.sum())                      # the one host sync of this check point
+            if n_live == 0 or steps == T:
+                break
+            if n_live < compact_below * rows.numel() and rows.numel() - n_live >= 8:
+                keep = live.nonzero().squeeze(1)
+                mem_cur, len_cur = mem_cur.index_select(1, keep), len_cur.index_select(0, keep)
+                sp = _make_spec(model, cfg, mem_cur, len_cur, max_length, params)
+                sp.training, sp.save, sp.temperature, sp.eval_rows, sp.seed = False, False, 1.0, 0, spec.seed
+                plan2, bufs2, ids2 = new_plan(sp, mem_cur)
+                NL, Bc, d3 = bufs["qkv"].shape[0], rows.numel(), bufs["qkv"].shape[2]
+                # the survivors' self-attention keys / values of the steps so far, and their last tokens
+                bufs2["qkv"].view(NL, T, n_live, d3)[:, :steps] = bufs["qkv"].view(NL, T, Bc, d3)[:, :steps].index_select(2, keep)
+                ids2[:steps] = ids[:steps].index_select(1, keep)
+                rows = rows.index_select(0, keep)
+                plan, bufs, ids, spec = plan2, bufs2, ids2, sp
+    return out[:steps]
