@@ -400,8 +400,9 @@ typedef struct {
     void* dnf;                    /* [T][B, d] */
     /* greedy search (beam 1): onmt/translate/translator_wh.py:709-746 + onmt/translate/greedy_search.py:135-165.
      * greedy = 1 (forward-only plans): each step writes only the argmax token ids[step][b] (int32; no probability
-     * slab), and steps > 0 embed ids[step-1] by a lookup in `emb` (step 0 reads the one-hot <s> of in_all[0]).  Sentences are independent, so running
-     * finished ones on (instead of compacting the batch as the reference does) leaves the others unchanged. */
+     * slab), and steps > 0 embed ids[step-1] by a lookup in `emb` (step 0 reads the one-hot <s> of in_all[0]).
+     * Sentences are independent: the host drops finished ones between steps by building a smaller plan from the
+     * survivors' rows (decode_engine.greedy_decode_ids; reference: translator_wh.py:744-746). */
     int32_t* ids;                 /* [T][B] or NULL */
     int greedy;
     /* Two decodes of the same weights in ONE sweep (no reference counterpart: the reference runs them one after the
