@@ -71,6 +71,10 @@ class MSSRConfig:
     # not a reference flag: Trainer.train_wgan_step decodes the critics' fake text and the generator phase's texts in
     # one sweep (False: the two phases run back to back exactly as train_discriminator + train_generator)
     share_decode_sweep: bool = True
+    # not a reference flag: train_discriminator runs each critic ONCE on its real, fake and interpolated inputs
+    # batched behind the embedding layer and backpropagates the summed objective once (the reference: three forward /
+    # backward passes per critic, onmt/trainer_wgan_wh.py:545-620); same losses and gradients up to summation order
+    batch_critic_passes: bool = True
     # not a reference flag: the style critic computes in fp32 even when the compute dtype is bf16
     style_critic_fp32: bool = True
 

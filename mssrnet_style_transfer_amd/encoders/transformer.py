@@ -60,8 +60,13 @@ class TransformerEncoder(EncoderBase):
     def forward(self, src, lengths=None):
         """src: Long [L, B, 1] or float [L, B, V]; lengths Long [B]."""
         self._check_args(src, lengths)
-        emb = self.embeddings(src)
-        pad = ~sequence_mask(lengths, max_len=src.size(0))                 # [B, L], True = padding
+        return self.forward_embedded(self.embeddings(src), lengths)
+
+    def forward_embedded(self, emb, lengths):
+        """The encoder behind its embedding layer: emb [L, B, d] (``self.embeddings`` of ids or of soft words, possibly
+        of several inputs concatenated along the batch) -> (emb, memory_bank, lengths).  No reference counterpart as a
+        method: it is the body of onmt/encoders/transformer.py:118-129 after the embedding call."""
+        pad = ~sequence_mask(lengths, max_len=emb.size(0))                 # [B, L], True = padding
         out = run_stack(self, emb.transpose(0, 1), pad)                    # all layers + final LN: one C call
         if out is None:                                                    # second-order graphs, long sequences
             out = emb.transpose(0, 1).contiguous()

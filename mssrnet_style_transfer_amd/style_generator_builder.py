@@ -57,6 +57,11 @@ class StyleClassifier(nn.Module):
         _, memory_bank, _ = self.encoder(src, src_lengths)
         return self.do_cls(memory_bank.transpose(0, 1), src_lengths)
 
+    def forward_embedded(self, emb, src_lengths):
+        """forward() on inputs that are embedded already (several texts batched behind the embedding layer)."""
+        _, memory_bank, _ = self.encoder.forward_embedded(emb, src_lengths)
+        return self.do_cls(memory_bank.transpose(0, 1), src_lengths)
+
 
 class StyleDiscriminator(nn.Module):
     def __init__(self, num_styles, opt):

@@ -273,6 +273,16 @@ class Trainer:
         real_rep_t = self._gen_real_style_represents(real_src, real_len).transpose(0, 1)
         gen_rep_t = rep.transpose(0, 1)
 
+        if cfg.batch_critic_passes:
+            if _shared is not None:
+                probs = _shared[1]
+            else:
+                with torch.no_grad():
+                    probs, _, _ = self._dynamic_decoding(real_src, real_len, rep, vocab_target.size(0))
+            gain_t_real, gain_t_fake, t_gp = self._text_critic_batched(vocab_target, probs, text_len, labels_list, alpha_t)
+            gain_s_real, gain_s_fake, s_gp = self._style_critic_batched(real_rep_t, gen_rep_t, real_len, labels_list,
+                                                                        alpha_s)
+            return self._finish_discriminator(gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp)
         # text critic: real / fake / gradient penalty
         gain_t_real = cal_disc_loss(self._call_text_discriminator(vocab_target, text_len), labels_list).mean()
         gain_t_real.backward(self.mone)
@@ -302,6 +312,62 @@ class Trainer:
                                        gp_norm_seq=cfg.use_gp_norm_seq, alpha=alpha_s)
         self._arm(self.style_discriminator)
         s_gp.backward()
+        return self._finish_discriminator(gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp)
+
+    def _penalty(self, g, lengths, max_len, k, lamb):
+        """gradient penalty of per-token input gradients g [B, L, dim] (penalize_gen_*_grad, :1253-1261, :1321-1329)."""
+        if self.cfg.use_gp_norm_seq:
+            return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
+                                   sequence_mask(lengths, max_len=max_len).contiguous().view(-1), k, lamb)
+        return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
+
+    def _text_critic_batched(self, vocab_target, probs, text_len, labels, alpha_t):
+        """The text critic's three passes of train_discriminator (real ids :545-551, fake soft words :553-560,
+        interpolated :562-569 / :1283-1331) as ONE pass on [T, 3B] rows: the real ids go through the embedding lookup
+        (so the padding row still receives no gradient from them), fake and interpolated words through the soft
+        product, and the encoder runs once on the concatenation.  Sentences are independent in the critic, so the
+        input gradient of the interpolated rows is the gradient penalty's and one backward of
+        fake - real + penalty accumulates what the reference's three backward calls do."""
+        cfg = self.cfg
+        B = labels.numel()
+        critic = self.text_discriminator
+        with torch.no_grad():
+            real_onehot = convert_sent_ids_to_onehot(vocab_target.transpose(0, 1).squeeze(2), cfg.vocab_size)
+            alpha = _to_device_async(alpha_t, real_onehot)
+            inter = (alpha * real_onehot + (1 - alpha) * probs.transpose(0, 1)).transpose(0, 1)
+        inter = inter.detach().requires_grad_(True)                                   # [T, B, V]
+        with ops.second_order():
+            emb = torch.cat([critic.encoder.embeddings(vocab_target),
+                             critic.encoder.embeddings(torch.cat([probs.to(inter.dtype), inter], 1))], 1)
+            gains = self._gain(critic.forward_embedded(emb, text_len.repeat(3)), cfg.gain_mode_t)
+            picked = cal_disc_loss(gains, labels.repeat(3))
+        err = picked[2 * B:]
+        g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+        gp = self._penalty(g.transpose(0, 1), text_len, vocab_target.size(0), cfg.wgan_text_k, cfg.wgan_text_lamb)
+        gain_real, gain_fake = picked[:B].mean(), picked[B:2 * B].mean()
+        self._arm(critic)
+        (gain_fake - gain_real + gp).backward()
+        return gain_real, gain_fake, gp
+
+    def _style_critic_batched(self, real_rep_t, gen_rep_t, lengths, labels, alpha_s):
+        """The style critic on real, generated and interpolated representations [B, L, dim] in one pass (:571-620)."""
+        cfg = self.cfg
+        B = labels.numel()
+        real, fake = real_rep_t.float(), gen_rep_t.float()
+        alpha = _to_device_async(alpha_s, real)
+        inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
+        with ops.second_order():
+            picked = cal_disc_loss(self._call_style_discriminator(torch.cat([real, fake, inter]), lengths.repeat(3)),
+                                   labels.repeat(3))
+        err = picked[2 * B:]
+        g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+        gp = self._penalty(g, lengths, real.size(1), cfg.wgan_style_k, cfg.wgan_style_lamb)
+        gain_real, gain_fake = picked[:B].mean(), picked[B:2 * B].mean()
+        self._arm(self.style_discriminator)
+        (gain_fake - gain_real + gp).backward()
+        return gain_real, gain_fake, gp
+
+    def _finish_discriminator(self, gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp):
         self._finish((self.style_discriminator, self.text_discriminator),
                      (self.style_discriminator_optim, self.text_discriminator_optim))
         return PhaseLog(("TR_gain", "TF_gain", "T_gp", "SR_gain", "SF_gain", "S_gp"),

@@ -125,6 +125,23 @@ def test_generator_phase_reference_order_fp32(ops, golden_phases):
         assert_grads(grads_of(nets[n]), c["grads"][n], 2e-4, "generator(ref order)." + n)
 
 
+def test_discriminator_phase_reference_order_fp32(ops, golden_phases):
+    """train_discriminator in the reference's own call order (each critic three times: real, fake, interpolated, with
+    a backward after each; batch_critic_passes = False) against the same golden vectors as the batched default."""
+    from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
+    cfg = MSSRConfig.small(batch_critic_passes=False)
+    nets = make_nets(golden_phases, cfg)
+    tr = Trainer(nets, cfg)
+    c = golden_phases["discriminator"]
+    torch.manual_seed(c["seed"])
+    random.seed(c["seed"])
+    log = tr.train_discriminator(gpu_batch(golden_phases))
+    for k, v in c["scalars"].items():
+        assert abs(log[k] - v) <= TOL * max(abs(v), 1e-3), (k, log[k], v)
+    for n in ("text_discriminator", "style_discriminator"):
+        assert_grads(grads_of(nets[n]), c["grads"][n], 2e-4, "discriminator(ref order)." + n)
+
+
 def test_reconstruct_phase_reference_order_fp32(ops, golden_phases):
     """train_reconstruct in the reference's own call order (two style-generator calls, three encoder calls,
     two decodes: batch_generator_phase = False) against the same golden vectors."""
