@@ -10,7 +10,8 @@
 // asks for the probabilities (the module returns them).  Backward recomputes the probabilities from
 // Q and K, keeps dS and the dropped probabilities of the head in LDS, and restages Q and dO over K
 // and V for the key / value gradients -- no atomics, no accumulators in memory.
-#include "common.hpp"
+#include "attention_common.hpp"
+#include <stdlib.h>
 
 namespace mssr {
 
@@ -29,21 +30,6 @@ static inline size_t fa_bwd_lds(int Lq, int Lk, int dh, size_t es) {
     const int Lm = Lq > Lk ? Lq : Lk;
     return 2 * (size_t)Lm * (dh + pad) * es + 2 * (size_t)Lq * Lk * sizeof(float) +
            4 * (size_t)(2 * FA_MAXL + 2 * FA_MAXD) * sizeof(float);
-}
-
-struct AttnArgs {
-    const void *q, *k, *v;
-    const uint8_t* mask;
-    int B, H, Lq, Lk, dh;
-    int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, mask_bs, mask_qs;
-    float scale, p_drop;
-    uint64_t seed;
-};
-
-__device__ __forceinline__ float fa_keep(const AttnArgs& a, int bh, int i, int t) {
-    if (a.p_drop <= 0.f) return 1.0f;
-    const uint32_t thr = drop_thr16(a.p_drop);
-    return keep16(a.seed, ((uint64_t)bh * a.Lq + i) * FA_MAXL + t, thr) ? 1.0f / (1.0f - a.p_drop) : 0.f;
 }
 
 // stage rows [0, n) of a [n, dh] head slice (row stride ls) into an LDS tile with row stride dh + pad
@@ -216,7 +202,22 @@ static void fa_args(const mssr_attn_desc* d, AttnArgs& a) {
 
 using namespace mssr;
 
+// 1: prefer the matrix-core kernels wherever they fit (MSSR_ATTN_MFMA=0: only beyond the scalar kernels' reach)
+static bool prefer_mfma() {
+    static const bool on = [] {
+        const char* e = getenv("MSSR_ATTN_MFMA");
+        return !e || atoi(e) != 0;
+    }();
+    return on;
+}
+static int scalar_fits(int Lq, int Lk, int dh, int dtype, int backward);
+
 extern "C" int mssr_attention_fits(int Lq, int Lk, int dh, int dtype, int backward) {
+    if (valid_dtype(dtype) && attn_mfma_fits(Lq, Lk, dh, dtype, backward)) return 1;
+    return scalar_fits(Lq, Lk, dh, dtype, backward);
+}
+
+static int scalar_fits(int Lq, int Lk, int dh, int dtype, int backward) {
     if (!valid_dtype(dtype) || Lq < 1 || Lk < 1 || Lk > FA_MAXL || dh < 4 || dh > FA_MAXD || dh % 4 != 0) return 0;
     if (backward && Lq > FA_MAXL) return 0;
     const size_t need = backward ? fa_bwd_lds(Lq, Lk, dh, dsize(dtype)) : fa_fwd_lds(Lk, dh, dsize(dtype));
@@ -227,7 +228,14 @@ extern "C" int mssr_attention_fwd(const mssr_attn_desc* d, void* ctx, int64_t ct
                                   void* stream) {
     if (int e = fa_check("attention_fwd", d)) return e;
     MSSR_REQUIRE(ctx, "attention_fwd: null output");
-    MSSR_REQUIRE(mssr_attention_fits(d->Lq, d->Lk, d->dh, d->dtype, 0),
+    {
+        AttnArgs a;
+        fa_args(d, a);
+        const bool scalar_ok = scalar_fits(d->Lq, d->Lk, d->dh, d->dtype, 0);
+        if ((prefer_mfma() || !scalar_ok) && attn_mfma_fwd_try(a, d->dtype, ctx, ctx_bs, ctx_ls, probs, (hipStream_t)stream))
+            MSSR_LAUNCH_OK("attention_fwd(mfma)");
+    }
+    MSSR_REQUIRE(scalar_fits(d->Lq, d->Lk, d->dh, d->dtype, 0),
                  "attention_fwd: Lk=%d dh=%d does not fit the fused kernel (<= %d keys, <= %d features, 64 KB LDS)",
                  d->Lk, d->dh, FA_MAXL, FA_MAXD);
     AttnArgs a;
@@ -248,7 +256,15 @@ extern "C" int mssr_attention_bwd(const mssr_attn_desc* d, const void* dctx, int
     MSSR_REQUIRE(dctx && dq && dk && dv, "attention_bwd: null pointer");
     MSSR_REQUIRE(dc_bs % 4 == 0 && dc_ls % 4 == 0 && aligned(dctx, 4 * dsize(d->dtype)),
                  "attention_bwd: dctx strides / alignment must be multiples of 4 elements");
-    MSSR_REQUIRE(mssr_attention_fits(d->Lq, d->Lk, d->dh, d->dtype, 1),
+    {
+        AttnArgs a;
+        fa_args(d, a);
+        const bool scalar_ok = scalar_fits(d->Lq, d->Lk, d->dh, d->dtype, 1);
+        if ((prefer_mfma() || !scalar_ok) &&
+            attn_mfma_bwd_try(a, d->dtype, dctx, dc_bs, dc_ls, dq, dq_bs, dq_ls, dk, dk_bs, dk_ls, dv, dv_bs, dv_ls, (hipStream_t)stream))
+            MSSR_LAUNCH_OK("attention_bwd(mfma)");
+    }
+    MSSR_REQUIRE(scalar_fits(d->Lq, d->Lk, d->dh, d->dtype, 1),
                  "attention_bwd: Lq=%d Lk=%d dh=%d does not fit the fused kernel", d->Lq, d->Lk, d->dh);
     AttnArgs a;
     fa_args(d, a);

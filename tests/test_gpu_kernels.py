@@ -363,11 +363,107 @@ def test_fused_attention_dropout_and_limits(ops):
     from mssrnet_style_transfer_amd import _lib
     lib = _lib.load()
     assert lib.mssr_attention_fits(17, 17, 64, _lib.BF16, 1) == 1
-    assert lib.mssr_attention_fits(130, 130, 64, _lib.BF16, 0) == 0
+    assert lib.mssr_attention_fits(130, 130, 64, _lib.BF16, 1) == 1          # matrix-core kernels (attention_mfma.hip)
+    assert lib.mssr_attention_fits(130, 130, 64, _lib.F32, 0) == 0
+    assert lib.mssr_attention_fits(161, 161, 64, _lib.BF16, 0) == 0
     big = torch.randn(2, 2, 70, 16, device="cuda")
     o_big, p_big = ops.attention(big, big, big, None, 0.0, False)          # composed path, same contract
     ref = torch.softmax(big @ big.transpose(-1, -2) / 4.0, -1) @ big
     assert_close(o_big, ref, 1e-4, "beyond the fused limits")
+
+
+def _attn_ref(q, k, v, mask, keep=None):
+    """fp64 reference of the attention chain on the bf16-rounded operands; keep = dropout multipliers or None."""
+    qr, kr, vr = (t.detach().double().requires_grad_(True) for t in (q, k, v))
+    sc = (qr / q.shape[-1] ** 0.5) @ kr.transpose(-1, -2)
+    if mask is not None:
+        sc = sc.masked_fill(mask.unsqueeze(1), -1e18)
+    pr = torch.softmax(sc, -1)
+    pd = pr if keep is None else pr * keep.double()
+    return (qr, kr, vr), pr, pd @ vr
+
+
+@pytest.mark.parametrize("B,H,Lq,Lk,dh,kind", [
+    (2, 2, 16, 16, 64, "pad"), (3, 2, 17, 17, 64, "pad"), (2, 4, 33, 50, 32, "none"), (2, 8, 130, 130, 64, "pad"),
+    (2, 2, 160, 160, 64, "causal"), (2, 3, 100, 37, 64, "pad"), (3, 2, 1, 140, 32, "pad"), (2, 2, 75, 129, 64, "full"),
+    (80, 8, 18, 18, 64, "pad")])
+def test_mfma_attention_bf16(ops, B, H, Lq, Lk, dh, kind):
+    """Matrix-core fused attention (csrc/attention_mfma.hip; bf16, up to 160 keys: the config-5 lengths) against fp64
+    torch on the same bf16 operands: context, probabilities, dq / dk / dv; key-padding, causal and per-query masks,
+    a fully masked sentence (uniform row, not NaN), ragged tile edges, one query row."""
+    from mssrnet_style_transfer_amd import _lib
+    assert _lib.load().mssr_attention_fits(Lq, Lk, dh, _lib.BF16, 1) == 1
+    torch.manual_seed(Lq * 1000 + Lk)
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        q, k, v = (torch.randn(B, n, H * dh, device="cuda").bfloat16().view(B, n, H, dh).transpose(1, 2).detach()
+                   .requires_grad_(True) for n in (Lq, Lk, Lk))
+        mask = None
+        if kind == "pad":
+            lens = torch.randint(1, Lk + 1, (B,), device="cuda")
+            lens[0] = Lk
+            mask = (torch.arange(Lk, device="cuda").unsqueeze(0) >= lens.unsqueeze(1)).unsqueeze(1)
+            mask[B - 1] = True                                                           # a fully masked sentence
+        elif kind == "causal":
+            mask = torch.triu(torch.ones(Lq, Lk, dtype=torch.bool, device="cuda"), 1).unsqueeze(0).repeat(B, 1, 1)
+        elif kind == "full":
+            mask = torch.rand(B, Lq, Lk, device="cuda") < 0.3
+        w = torch.randn(B, H, Lq, dh, device="cuda").bfloat16()
+        out, probs = ops.attention(q, k, v, mask, 0.0, False)
+        assert out.dtype == torch.bfloat16 and probs.dtype == torch.bfloat16
+        g = torch.autograd.grad((out * w).sum(), (q, k, v))
+        leaves, pr, ref = _attn_ref(q, k, v, mask)
+        gr = torch.autograd.grad((ref * w.double()).sum(), leaves)
+        assert torch.isfinite(out.float()).all() and torch.isfinite(probs.float()).all()
+        assert_close(out.float(), ref.float(), TOL16, "out")
+        assert_close(probs.float(), pr.float(), TOL16, "probs")
+        if kind == "pad":
+            assert_close(probs[B - 1].float(), torch.full_like(probs[B - 1], 1.0 / Lk).float(), 1e-2, "masked row uniform")
+        for name, a, b in zip("qkv", g, gr):
+            assert_close(a.float(), b.float(), 3e-2, "d" + name, floor=1e-6)
+    finally:
+        ops.set_compute_dtype(torch.float32)
+
+
+@pytest.mark.parametrize("Lq,Lk", [(40, 48), (130, 130)])
+def test_mfma_attention_dropout_replay(ops, Lq, Lk):
+    """Dropout inside the matrix-core kernels: the keep decisions are read off the forward (one-hot values: the context
+    IS the dropped probability row, 64 keys at a time under a fixed seed), then the backward of a random problem with
+    the same seed must equal fp64 autograd with exactly that mask -- both backward phases regenerate it."""
+    B, H, dh, p = 2, 3, 64, 0.3
+    torch.manual_seed(5)
+    ops.set_compute_dtype(torch.bfloat16)
+    try:
+        q, k, v = (torch.randn(B, n, H * dh, device="cuda").bfloat16().view(B, n, H, dh).transpose(1, 2).detach()
+                   .requires_grad_(True) for n in (Lq, Lk, Lk))
+        lens = torch.tensor([Lk, Lk - 5], device="cuda")
+        mask = (torch.arange(Lk, device="cuda").unsqueeze(0) >= lens.unsqueeze(1)).unsqueeze(1)
+        pd = torch.zeros(B, H, Lq, Lk, device="cuda")
+        with torch.no_grad():
+            for c0 in range(0, Lk, dh):
+                n = min(dh, Lk - c0)
+                onehot = torch.zeros(B, H, Lk, dh, device="cuda", dtype=torch.bfloat16)
+                onehot[:, :, c0:c0 + n, :n] = torch.eye(n, device="cuda", dtype=torch.bfloat16)
+                oh = onehot.transpose(1, 2).contiguous().transpose(1, 2)
+                ops._state["seed_counter"] = 123
+                o, probs = ops.attention(q.detach(), k.detach(), oh, mask, p, True)
+                pd[..., c0:c0 + n] = o[..., :n].float()
+        keep = (pd != 0).float() / (1.0 - p)
+        live = probs.float() > 1e-4
+        rate = float(((pd != 0) & live).sum()) / float(live.sum())
+        assert abs(rate - (1 - p)) < 0.02, rate
+        assert_close(pd, probs.float() * keep, TOL16, "dropped probabilities")
+        w = torch.randn(B, H, Lq, dh, device="cuda").bfloat16()
+        ops._state["seed_counter"] = 123
+        out, _ = ops.attention(q, k, v, mask, p, True)
+        g = torch.autograd.grad((out * w).sum(), (q, k, v))
+        leaves, _, ref = _attn_ref(q, k, v, mask, keep)
+        gr = torch.autograd.grad((ref * w.double()).sum(), leaves)
+        assert_close(out.float(), ref.float(), TOL16, "out")
+        for name, a, b in zip("qkv", g, gr):
+            assert_close(a.float(), b.float(), 3e-2, "d" + name, floor=1e-6)
+    finally:
+        ops.set_compute_dtype(torch.float32)
 
 
 @pytest.mark.parametrize("B,H,Lq,Lk,dh", [(1, 1, 1, 1, 8), (2, 3, 1, 64, 16), (2, 2, 64, 64, 64), (3, 2, 5, 7, 32),
