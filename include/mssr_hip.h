@@ -194,6 +194,33 @@ int mssr_colsum_batched(const void* x, float* out, int batch, int64_t x_bs, int6
 int mssr_axpby(const void* x, const void* z, void* y, int64_t n, float a, float b, int dtype,
                void* stream);
 
+/* ------------------------------------------------------------------ weight packs ----------
+ * Every derived copy of the fp32 master parameters that the engines read, refreshed in ONE launch after an
+ * optimizer step: compute-dtype copies packed into [layer][rows][k] slabs (Q|K|V rows of
+ * onmt/modules/multi_headed_attn.py:63-70 side by side, ...), their transposes (the k-contiguous operand of
+ * dX = dY W), LayerNorm folded into the Linear behind it (gamma * W, the row sums of the rounded values, W beta + b:
+ * onmt/encoders/transformer.py:47-52, onmt/decoders/transformer.py:110-171, onmt/modules/position_ffn.py:35-37)
+ * and fp32 copies of bias / LayerNorm vectors.  The reference has no counterpart: it reads the parameters in place.
+ * A job = one parameter tensor src [rows, cols] (row-major fp32) and where its copies go; every output pointer may
+ * be NULL.  The job table lives in DEVICE memory (built once per network: the pointers do not change), block0 =
+ * first block of the job in the launch, mssr_pack_blocks(rows) blocks per job, n_blocks = their sum. */
+typedef struct {
+    const float* src;
+    int32_t rows, cols;
+    void* dst;   int64_t dst_ld;      /* dst[r*dst_ld + c]     = T(src[r][c]) */
+    void* dst_t; int64_t dst_t_ld;    /* dst_t[c*dst_t_ld + r] = T(src[r][c]) */
+    void* dst_g; int64_t dst_g_ld;    /* dst_g[r*dst_g_ld + c] = T(src[r][c] * gamma[c]) */
+    const float* gamma;               /* [cols], with dst_g / colsum */
+    const float* beta;                /* [cols], with bias_f */
+    const float* bias;                /* [rows] or NULL, with bias_f */
+    float* colsum;                    /* [rows]  sum_c float(T(src[r][c] * gamma[c])) */
+    float* bias_f;                    /* [rows]  sum_c src[r][c] * beta[c] + bias[r] */
+    float* dst_f;                     /* [rows*cols] fp32 copy */
+    int32_t block0, pad_;
+} mssr_pack_job;
+int mssr_pack_blocks(int rows);
+int mssr_pack_weights(const mssr_pack_job* jobs_dev, int n_jobs, int n_blocks, int dtype, void* stream);
+
 /* ------------------------------------------------------- gradient norm, clipping, Adam -----
  * One optimizer step of a whole network: torch.nn.utils.clip_grad_norm_(params, max_norm) + torch.optim.Adam.step()
  * as built and called by the reference trainer (onmt/trainer_wgan_wh.py:192-211 Adam(lr, betas=(beta1, beta2)),

@@ -83,6 +83,14 @@ class AttnDesc(Structure):
                 ("p_drop", c_float), ("seed", c_uint64), ("dtype", c_int)]
 
 
+class PackJob(Structure):
+    """mssr_pack_job (include/mssr_hip.h)."""
+    _fields_ = [("src", c_void_p), ("rows", c_int), ("cols", c_int), ("dst", c_void_p), ("dst_ld", c_int64),
+                ("dst_t", c_void_p), ("dst_t_ld", c_int64), ("dst_g", c_void_p), ("dst_g_ld", c_int64),
+                ("gamma", c_void_p), ("beta", c_void_p), ("bias", c_void_p), ("colsum", c_void_p), ("bias_f", c_void_p),
+                ("dst_f", c_void_p), ("block0", c_int), ("pad_", c_int)]
+
+
 class ProfRecord(Structure):
     """mssr_prof_record (include/mssr_hip.h)."""
     _fields_ = [("kernel", c_int), ("in_dtype", c_int), ("out_dtype", c_int), ("tile", c_int), ("ksplit", c_int), ("ln", c_int),
@@ -114,6 +122,8 @@ SIGNATURES = {
     "mssr_grad_norm_scratch_floats": ([_I], c_int64),
     "mssr_grad_norm": ([_I, _P, _P, _F, _P, _P, _P], c_int),
     "mssr_adam_step": ([_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _I, _P], c_int),
+    "mssr_pack_blocks": ([_I], c_int),
+    "mssr_pack_weights": ([_P, _I, _I, _I, _P], c_int),
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
     "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),

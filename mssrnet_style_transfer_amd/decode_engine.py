@@ -24,6 +24,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import ops
+from .weight_pack import JobTable
 
 N_HEAD_PARAMS = 5
 N_LAYER_PARAMS = 26
@@ -56,7 +57,9 @@ def decoder_params(model):
 
 
 class _Pack:
-    """Decoder + generator weights as the engine wants them (compute dtype, packed, transposed)."""
+    """Decoder + generator weights as the engine wants them (compute dtype, packed, transposed, LN-folded).  The
+    buffers are allocated once; ``refresh()`` recomputes all of them from the fp32 parameters in one launch
+    (weight_pack.JobTable -> csrc/pack.hip)."""
 
     def __init__(self, params, n_layers, cd):
         E, lnFg, lnFb, Wg, bg = params[:N_HEAD_PARAMS]
@@ -66,60 +69,76 @@ class _Pack:
         V, d = E.shape
         ff = lp[0][_W1].shape[0]
         Vp = (V + 31) // 32 * 32
+        dev = E.device
         self.NL, self.V, self.Vp, self.d, self.ff, self.cd = NL, V, Vp, d, ff, cd
-        with torch.no_grad():
-            def rows(idx):          # rows of the given per-layer parameters, layer-major
-                return torch.cat([lp[l][i].detach() for l in range(NL) for i in idx], 0)
+        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        for name, n_out, n_in in (("qkv", 3 * d, d), ("so", d, d), ("cq", d, d), ("co", d, d), ("1", ff, d), ("2", d, ff)):
+            setattr(self, "w_" + name, e(NL, n_out, n_in))
+            setattr(self, "wt_" + name, e(NL, n_in, n_out))
+            setattr(self, "b_" + name, f(NL, n_out))
+        self.w_ckv, self.b_ckv = e(NL * 2 * d, d), f(NL * 2 * d)           # all layers' context keys|values: one product
+        self.wt_ckv = e(NL, d, 2 * d)
+        for name in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "lnf_g", "lnf_b"):
+            setattr(self, name, f(NL, d))
+        self.emb, self.w_gen = e(V, d), e(V, d)
+        self.emb_t = torch.zeros(d, Vp, dtype=cd, device=dev)              # columns V..Vp stay zero
+        self.wt_gen = torch.zeros(d, Vp, dtype=cd, device=dev)
+        self.b_gen, self.lnF_g, self.lnF_b = f(V), f(d), f(d)
+        # LayerNorm folded into the Linear behind it (bf16 skinny kernel, mssr_gemm_desc.ln_colsum):
+        # W' = gamma * W (rounded to bf16), colsum(W') of the ROUNDED values, bias' = W beta + b
+        self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
+        names = ["w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2",
+                 "wt_2", "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
+                 "lnf_g", "lnf_b"]
+        if self.fuse_ln:
+            for name, n_out in (("qkv", 3 * d), ("cq", d), ("1", ff)):
+                setattr(self, "wg_" + name, e(NL, n_out, d))
+                setattr(self, "cs_" + name, f(NL, n_out))
+                setattr(self, "bf_" + name, f(NL, n_out))
+            self.wg_gen, self.cs_gen, self.bf_gen = e(V, d), f(V), f(V)
+            names += ["wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1"]
 
-            def w(idx, n_out, n_in):
-                t = rows(idx).to(cd).view(NL, n_out, n_in)
-                return t, t.transpose(1, 2).contiguous()
+        jt = self.jobs = JobTable(cd, dev)
 
-            def f(idx, n):
-                return rows(idx).float().view(NL, n).contiguous()
+        def linear(l, name, w_idx, b_idx, off, ln=None):
+            """rows [off, off + n) of packed weight `name` of layer l <- parameter w_idx (+ bias b_idx); ln = (gamma
+            index, beta index): also the LayerNorm-folded copy"""
+            W, b = lp[l][w_idx], lp[l][b_idx]
+            n = W.shape[0]
+            kw = {}
+            if ln is not None and self.fuse_ln:
+                kw = dict(dst_g=getattr(self, "wg_" + name)[l, off:off + n], gamma=lp[l][ln[0]], beta=lp[l][ln[1]], bias=b,
+                          colsum=getattr(self, "cs_" + name)[l, off:off + n], bias_f=getattr(self, "bf_" + name)[l, off:off + n])
+            jt.add(W, dst=getattr(self, "w_" + name)[l, off:off + n], dst_t=getattr(self, "wt_" + name)[l][:, off:off + n], **kw)
+            jt.add(b, dst_f=getattr(self, "b_" + name)[l, off:off + n])
 
-            self.w_qkv, self.wt_qkv = w([_WQ, _WK, _WV], 3 * d, d)
-            self.w_so, self.wt_so = w([_WSO], d, d)
-            self.w_cq, self.wt_cq = w([_WCQ], d, d)
-            self.w_co, self.wt_co = w([_WCO], d, d)
-            self.w_1, self.wt_1 = w([_W1], ff, d)
-            self.w_2, self.wt_2 = w([_W2], d, ff)
-            self.w_ckv = rows([_WCK, _WCV]).to(cd).contiguous()            # [NL*2d, d]
-            self.b_ckv = rows([_BCK, _BCV]).float().contiguous()           # [NL*2d]
-            self.b_qkv, self.b_so, self.b_cq, self.b_co = f([_BQ, _BK, _BV], 3 * d), f([_BSO], d), f([_BCQ], d), \
-                f([_BCO], d)
-            self.b_1, self.b_2 = f([_B1], ff), f([_B2], d)
-            self.ln1_g, self.ln1_b, self.ln2_g, self.ln2_b = f([_LN1G], d), f([_LN1B], d), f([_LN2G], d), f([_LN2B], d)
-            self.lnf_g, self.lnf_b = f([_LNFG], d), f([_LNFB], d)
-            self.emb = E.detach().to(cd).contiguous()                      # [V, d]
-            self.emb_t = torch.zeros(d, Vp, dtype=cd, device=E.device)
-            self.emb_t[:, :V] = self.emb.t()
-            self.w_gen = Wg.detach().to(cd).contiguous()                   # [V, d]
-            self.wt_gen = torch.zeros(d, Vp, dtype=cd, device=E.device)
-            self.wt_gen[:, :V] = self.w_gen.t()
-            self.b_gen = bg.detach().float().contiguous()
-            self.lnF_g, self.lnF_b = lnFg.detach().float().contiguous(), lnFb.detach().float().contiguous()
-            # LayerNorm folded into the Linear behind it (bf16 skinny kernel, mssr_gemm_desc.ln_colsum):
-            # W' = gamma * W (rounded to bf16), colsum(W') of the ROUNDED values, bias' = W beta + b
-            self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
-            names = ["w_qkv", "wt_qkv", "w_so", "wt_so", "w_cq", "wt_cq", "w_co", "wt_co", "w_1", "wt_1", "w_2",
-                     "wt_2", "b_qkv", "b_so", "b_cq", "b_co", "b_1", "b_2", "ln1_g", "ln1_b", "ln2_g", "ln2_b",
-                     "lnf_g", "lnf_b"]
-            if self.fuse_ln:
-                def fold(idx, n_out, g, b, bias):
-                    w32 = rows(idx).float().view(NL, n_out, d)
-                    wg = (w32 * g.unsqueeze(1)).to(cd).contiguous()
-                    return wg, wg.float().sum(-1).contiguous(), (torch.bmm(w32, b.unsqueeze(2)).squeeze(2) + bias).contiguous()
+        for l in range(NL):
+            linear(l, "qkv", _WQ, _BQ, 0, (_LN1G, _LN1B))
+            linear(l, "qkv", _WK, _BK, d, (_LN1G, _LN1B))
+            linear(l, "qkv", _WV, _BV, 2 * d, (_LN1G, _LN1B))
+            linear(l, "so", _WSO, _BSO, 0)
+            linear(l, "cq", _WCQ, _BCQ, 0, (_LN2G, _LN2B))
+            linear(l, "co", _WCO, _BCO, 0)
+            linear(l, "1", _W1, _B1, 0, (_LNFG, _LNFB))
+            linear(l, "2", _W2, _B2, 0)
+            for i, (w_idx, b_idx) in enumerate(((_WCK, _BCK), (_WCV, _BCV))):
+                r0 = (2 * l + i) * d
+                jt.add(lp[l][w_idx], dst=self.w_ckv[r0:r0 + d], dst_t=self.wt_ckv[l][:, i * d:(i + 1) * d])
+                jt.add(lp[l][b_idx], dst_f=self.b_ckv[r0:r0 + d])
+            for name, idx in (("ln1_g", _LN1G), ("ln1_b", _LN1B), ("ln2_g", _LN2G), ("ln2_b", _LN2B), ("lnf_g", _LNFG),
+                              ("lnf_b", _LNFB)):
+                jt.add(lp[l][idx], dst_f=getattr(self, name)[l])
+        jt.add(E, dst=self.emb, dst_t=self.emb_t[:, :V])
+        kw = {}
+        if self.fuse_ln:
+            kw = dict(dst_g=self.wg_gen, gamma=lnFg, beta=lnFb, bias=bg, colsum=self.cs_gen, bias_f=self.bf_gen)
+        jt.add(Wg, dst=self.w_gen, dst_t=self.wt_gen[:, :V], **kw)
+        jt.add(bg, dst_f=self.b_gen)
+        jt.add(lnFg, dst_f=self.lnF_g)
+        jt.add(lnFb, dst_f=self.lnF_b)
+        jt.finish()
 
-                self.wg_qkv, self.cs_qkv, self.bf_qkv = fold([_WQ, _WK, _WV], 3 * d, self.ln1_g, self.ln1_b, self.b_qkv)
-                self.wg_cq, self.cs_cq, self.bf_cq = fold([_WCQ], d, self.ln2_g, self.ln2_b, self.b_cq)
-                self.wg_1, self.cs_1, self.bf_1 = fold([_W1], ff, self.lnf_g, self.lnf_b, self.b_1)
-                wg32 = Wg.detach().float()
-                self.wg_gen = (wg32 * self.lnF_g).to(cd).contiguous()
-                self.cs_gen = self.wg_gen.float().sum(-1).contiguous()
-                self.bf_gen = (wg32 @ self.lnF_b + self.b_gen).contiguous()
-                names += ["wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1"]
-            self.wt_ckv = self.w_ckv.view(NL, 2 * d, d).transpose(1, 2).contiguous()      # [NL, d, 2d]
         arr = (L.DecLayer * NL)()
         for l in range(NL):
             for name in names:
@@ -127,13 +146,22 @@ class _Pack:
         self.layers = arr
         # The transposed copies double as the k-contiguous operand of dX = dY W on the MODULE path (the
         # teacher-forced decoder of the same model in the reconstruct phase): ops._Matmul finds them by parameter.
+        self._transposed = []
         for l in range(NL):
             for idx, wt, lo in ((_WQ, self.wt_qkv, 0), (_WK, self.wt_qkv, d), (_WV, self.wt_qkv, 2 * d),
                                 (_WSO, self.wt_so, 0), (_WCQ, self.wt_cq, 0), (_WCO, self.wt_co, 0),
                                 (_W1, self.wt_1, 0), (_W2, self.wt_2, 0), (_WCK, self.wt_ckv, 0), (_WCV, self.wt_ckv, d)):
                 w_p = lp[l][idx]
                 if isinstance(w_p, torch.nn.Parameter):
-                    ops.register_transposed(w_p, wt[l][:, lo:lo + w_p.shape[0]])
+                    self._transposed.append((w_p, wt[l][:, lo:lo + w_p.shape[0]]))
+        self.refresh()
+
+    def refresh(self):
+        """Recompute every buffer from the current parameter values (one launch) and renew the transposed-weight
+        registrations, which are valid for one parameter version."""
+        self.jobs.run()
+        for w_p, wt in self._transposed:
+            ops.register_transposed(w_p, wt)
 
 
 _pack_cache = {}
@@ -149,14 +177,23 @@ def _pack_version(cd, params):
 
 
 def cached_pack(cache, owner, params, build):
-    """``build()`` once per (owner object, parameter versions).  Entries are keyed by ``id(owner)`` but
-    only trusted while the weak reference stored beside them still resolves to ``owner`` itself, and
-    they are dropped (with the GPU memory of the pack) when the owner is garbage collected."""
-    ver = _pack_version(ops.compute_dtype(), params)
+    """The pack of ``owner`` for the current parameter values.  Entries are keyed by ``id(owner)`` but only trusted
+    while the weak reference stored beside them still resolves to ``owner`` itself, and they are dropped (with the GPU
+    memory of the pack) when the owner is garbage collected.  New VALUES in the same tensors (an optimizer step)
+    refresh the pack's buffers in place -- one launch -- unless an autograd graph that was built on them is still
+    waiting for its backward (``JobTable.pin``): then a fresh pack is built and the old one stays with that graph."""
+    cd = ops.compute_dtype()
+    ver = _pack_version(cd, params)
     key = id(owner)
     hit = cache.get(key)
-    if hit is not None and hit[2]() is owner and hit[0] == ver:
-        return hit[1]
+    if hit is not None and hit[2]() is owner:
+        if hit[0] == ver:
+            return hit[1]
+        old = hit[1]
+        if old.cd == cd and hit[0][3] == ver[3] and not old.jobs.pinned():
+            old.refresh()
+            cache[key] = (ver, old, hit[2])
+            return old
     pack = build()
     ref = weakref.ref(owner)
     cache[key] = (ver, pack, ref)
@@ -269,6 +306,7 @@ class _SoftDecode(Function):
         probs = bufs.pop("probs")
         if spec.save:
             ctx.spec, ctx.plan, ctx.bufs = spec, plan, bufs
+            ctx.pin = spec.pack.jobs.pin()      # the backward reads the pack: no in-place refresh until then
             ctx.mem_meta = (mem.shape, mem.dtype)
             ctx.save_for_backward(probs)        # read by the softmax backward of every step
         return probs
@@ -379,7 +417,7 @@ class _SoftDecode(Function):
                     gW_1[l], gb_1[l], gW_2[l], gb_2[l],
                     ln_g[3 * l, 0], ln_g[3 * l, 1], ln_g[3 * l + 1, 0], ln_g[3 * l + 1, 1], ln_g[3 * l + 2, 0],
                     ln_g[3 * l + 2, 1]]
-        ctx.bufs = ctx.plan = None
+        ctx.bufs = ctx.plan = ctx.pin = None
         return tuple(out)
 
 

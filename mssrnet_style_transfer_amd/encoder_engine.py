@@ -19,6 +19,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib as L
 from . import ops
 from .decode_engine import _bgemm_t, _bsum, cached_pack
+from .weight_pack import JobTable
 
 N_ENC_LAYER_PARAMS = 16
 (_WQ, _BQ, _WK, _BK, _WV, _BV, _WO, _BO, _W1, _B1, _W2, _B2, _LNFG, _LNFB, _LN1G, _LN1B) = range(N_ENC_LAYER_PARAMS)
@@ -43,7 +44,8 @@ def encoder_params(enc):
 
 
 class _Pack:
-    """Encoder-stack weights as the engine wants them (compute dtype, packed, transposed, LN-folded)."""
+    """Encoder-stack weights as the engine wants them (compute dtype, packed, transposed, LN-folded): buffers
+    allocated once, refreshed from the fp32 parameters in one launch (weight_pack.JobTable -> csrc/pack.hip)."""
 
     def __init__(self, params, n_layers, cd):
         lnFg, lnFb = params[:2]
@@ -51,42 +53,60 @@ class _Pack:
         NL = n_layers
         d = lp[0][_WQ].shape[1]
         ff = lp[0][_W1].shape[0]
+        dev = lnFg.device
         self.NL, self.d, self.ff, self.cd = NL, d, ff, cd
-        with torch.no_grad():
-            def rows(idx):
-                return torch.cat([lp[l][i].detach() for l in range(NL) for i in idx], 0)
+        e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
+        for name, n_out, n_in in (("qkv", 3 * d, d), ("o", d, d), ("1", ff, d), ("2", d, ff)):
+            setattr(self, "w_" + name, e(NL, n_out, n_in))
+            setattr(self, "wt_" + name, e(NL, n_in, n_out))
+            setattr(self, "b_" + name, f(NL, n_out))
+        for name in ("ln1_g", "ln1_b", "lnf_g", "lnf_b"):
+            setattr(self, name, f(NL, d))
+        self.lnF_g, self.lnF_b = f(d), f(d)
+        names = ["w_qkv", "wt_qkv", "w_o", "wt_o", "w_1", "wt_1", "w_2", "wt_2", "b_qkv", "b_o", "b_1", "b_2",
+                 "ln1_g", "ln1_b", "lnf_g", "lnf_b"]
+        self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
+        if self.fuse_ln:
+            for name, n_out in (("qkv", 3 * d), ("1", ff)):
+                setattr(self, "wg_" + name, e(NL, n_out, d))
+                setattr(self, "cs_" + name, f(NL, n_out))
+                setattr(self, "bf_" + name, f(NL, n_out))
+            names += ["wg_qkv", "wg_1", "cs_qkv", "cs_1", "bf_qkv", "bf_1"]
 
-            def w(idx, n_out, n_in):
-                t = rows(idx).to(cd).view(NL, n_out, n_in)
-                return t, t.transpose(1, 2).contiguous()
+        jt = self.jobs = JobTable(cd, dev)
 
-            def f(idx, n):
-                return rows(idx).float().view(NL, n).contiguous()
+        def linear(l, name, w_idx, b_idx, off, ln=None):
+            W, b = lp[l][w_idx], lp[l][b_idx]
+            n = W.shape[0]
+            kw = {}
+            if ln is not None and self.fuse_ln:
+                kw = dict(dst_g=getattr(self, "wg_" + name)[l, off:off + n], gamma=lp[l][ln[0]], beta=lp[l][ln[1]], bias=b,
+                          colsum=getattr(self, "cs_" + name)[l, off:off + n], bias_f=getattr(self, "bf_" + name)[l, off:off + n])
+            jt.add(W, dst=getattr(self, "w_" + name)[l, off:off + n], dst_t=getattr(self, "wt_" + name)[l][:, off:off + n], **kw)
+            jt.add(b, dst_f=getattr(self, "b_" + name)[l, off:off + n])
 
-            self.w_qkv, self.wt_qkv = w([_WQ, _WK, _WV], 3 * d, d)
-            self.w_o, self.wt_o = w([_WO], d, d)
-            self.w_1, self.wt_1 = w([_W1], ff, d)
-            self.w_2, self.wt_2 = w([_W2], d, ff)
-            self.b_qkv, self.b_o, self.b_1, self.b_2 = f([_BQ, _BK, _BV], 3 * d), f([_BO], d), f([_B1], ff), f([_B2], d)
-            self.ln1_g, self.ln1_b, self.lnf_g, self.lnf_b = f([_LN1G], d), f([_LN1B], d), f([_LNFG], d), f([_LNFB], d)
-            self.lnF_g, self.lnF_b = lnFg.detach().float().contiguous(), lnFb.detach().float().contiguous()
-            names = ["w_qkv", "wt_qkv", "w_o", "wt_o", "w_1", "wt_1", "w_2", "wt_2", "b_qkv", "b_o", "b_1", "b_2",
-                     "ln1_g", "ln1_b", "lnf_g", "lnf_b"]
-            self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
-            if self.fuse_ln:
-                def fold(idx, n_out, g, b, bias):
-                    w32 = rows(idx).float().view(NL, n_out, d)
-                    wg = (w32 * g.unsqueeze(1)).to(cd).contiguous()
-                    return wg, wg.float().sum(-1).contiguous(), (torch.bmm(w32, b.unsqueeze(2)).squeeze(2) + bias).contiguous()
-
-                self.wg_qkv, self.cs_qkv, self.bf_qkv = fold([_WQ, _WK, _WV], 3 * d, self.ln1_g, self.ln1_b, self.b_qkv)
-                self.wg_1, self.cs_1, self.bf_1 = fold([_W1], ff, self.lnf_g, self.lnf_b, self.b_1)
-                names += ["wg_qkv", "wg_1", "cs_qkv", "cs_1", "bf_qkv", "bf_1"]
+        for l in range(NL):
+            linear(l, "qkv", _WQ, _BQ, 0, (_LN1G, _LN1B))
+            linear(l, "qkv", _WK, _BK, d, (_LN1G, _LN1B))
+            linear(l, "qkv", _WV, _BV, 2 * d, (_LN1G, _LN1B))
+            linear(l, "o", _WO, _BO, 0)
+            linear(l, "1", _W1, _B1, 0, (_LNFG, _LNFB))
+            linear(l, "2", _W2, _B2, 0)
+            for name, idx in (("ln1_g", _LN1G), ("ln1_b", _LN1B), ("lnf_g", _LNFG), ("lnf_b", _LNFB)):
+                jt.add(lp[l][idx], dst_f=getattr(self, name)[l])
+        jt.add(lnFg, dst_f=self.lnF_g)
+        jt.add(lnFb, dst_f=self.lnF_b)
+        jt.finish()
         arr = (L.EncLayer * NL)()
         for l in range(NL):
             for name in names:
                 setattr(arr[l], name, getattr(self, name)[l].data_ptr())
         self.layers = arr
+        self.refresh()
+
+    def refresh(self):
+        self.jobs.run()
 
 
 _pack_cache = {}
@@ -131,6 +151,7 @@ class _EncoderStack(Function):
         out = bufs.pop("out")
         if spec.save:
             ctx.spec, ctx.plan, ctx.bufs = spec, plan, bufs
+            ctx.pin = pk.jobs.pin()             # the backward reads the pack: no in-place refresh until then
             ctx.x_dtype = x.dtype
         return out.view(B, Ln, d)
 
@@ -178,7 +199,7 @@ class _EncoderStack(Function):
             out += [gW_qkv[l, :d], gb_qkv[l, :d], gW_qkv[l, d:2 * d], gb_qkv[l, d:2 * d], gW_qkv[l, 2 * d:],
                     gb_qkv[l, 2 * d:], gW_o[l], gb_o[l], gW_1[l], gb_1[l], gW_2[l], gb_2[l],
                     ln_g[2 * l + 1, 0], ln_g[2 * l + 1, 1], ln_g[2 * l, 0], ln_g[2 * l, 1]]
-        ctx.bufs = ctx.plan = None
+        ctx.bufs = ctx.plan = ctx.pin = None
         return tuple(out)
 
 

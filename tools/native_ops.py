@@ -1,0 +1,68 @@
+"""Which Python lines issue aten ops that launch kernels which are NOT ours (at::native elementwise / reduce / cat /
+copies / fills, hipBLASLt) in one WGAN step.  A TorchDispatchMode counts every non-view aten call by
+(op, innermost frame inside the package); autograd worker threads inherit the mode.
+python tools/native_ops.py [--workload wgan|reconstruct]"""
+import collections
+import os
+import sys
+import traceback
+
+import torch
+from torch.utils._python_dispatch import TorchDispatchMode
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from mssrnet_style_transfer_amd import ops  # noqa: E402
+from mssrnet_style_transfer_amd.config import MSSRConfig  # noqa: E402
+from mssrnet_style_transfer_amd.style_generator_builder import build_all  # noqa: E402
+from mssrnet_style_transfer_amd.synth import make_batch  # noqa: E402
+from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer  # noqa: E402
+
+VIEWS = {"view", "_unsafe_view", "as_strided", "slice", "select", "transpose", "permute", "expand", "unsqueeze", "squeeze",
+         "detach", "alias", "t", "reshape", "empty", "empty_like", "empty_strided", "new_empty", "new_empty_strided",
+         "unbind", "split", "split_with_sizes", "narrow", "unfold", "view_as_real", "_reshape_alias", "lift_fresh",
+         "is_same_size", "stride", "size", "sym_size", "numel", "dim", "is_contiguous", "diagonal", "chunk", "unsafe_split",
+         "unsafe_chunk", "result_type", "_local_scalar_dense", "is_nonzero", "item", "resize_", "set_", "record_stream",
+         "is_pinned", "_has_compatible_shallow_copy_type", "sym_numel", "sym_stride", "sym_storage_offset"}
+
+
+class Count(TorchDispatchMode):
+    def __init__(self):
+        super().__init__()
+        self.agg = collections.OrderedDict()
+
+    def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+        name = func.__name__.split(".")[0]
+        if name not in VIEWS:
+            frames = traceback.extract_stack()
+            fr = next((f for f in reversed(frames) if "mssrnet_style_transfer_amd" in f.filename), None)
+            where = "%s:%d %s" % (os.path.relpath(fr.filename, ROOT), fr.lineno, fr.name) if fr else "(autograd / torch)"
+            shp = [tuple(a.shape) for a in args if isinstance(a, torch.Tensor)][:3]
+            a = self.agg.setdefault((name, where), [0, shp])
+            a[0] += 1
+        return func(*args, **(kwargs or {}))
+
+
+def main():
+    wl = sys.argv[sys.argv.index("--workload") + 1] if "--workload" in sys.argv else "wgan"
+    ops.set_compute_dtype(torch.bfloat16)
+    cfg = MSSRConfig()
+    nets = build_all(cfg, device="cuda", seed=123)
+    batch = make_batch(80, 16, cfg.vocab_size, seed=123, device="cuda")
+    trainer = Trainer(nets, cfg)
+    step = (lambda: trainer.train_wgan_step(batch)) if wl == "wgan" else (lambda: trainer.train_reconstruct(batch))
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    c = Count()
+    with c:
+        step()
+        torch.cuda.synchronize()
+    tot = sum(v[0] for v in c.agg.values())
+    print("aten calls that may launch: %d" % tot)
+    for (op, where), (n, shp) in sorted(c.agg.items(), key=lambda kv: -kv[1][0])[:160]:
+        print("%4d  %-24s %-78s %s" % (n, op, where, shp))
+
+
+if __name__ == "__main__":
+    main()
