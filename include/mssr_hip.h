@@ -242,6 +242,10 @@ int mssr_grad_norm(int n, void* const* grads, const int64_t* numels, float max_n
 int mssr_adam_step(int n, void* const* params, void* const* grads, const int64_t* numels,
                    const int64_t* state_offsets, float* exp_avg, float* exp_avg_sq, const float* norm_coef, float lr,
                    float beta1, float beta2, float eps, const int32_t* steps, int write_clipped, void* stream);
+/* dst[i][:] = scale * src[i][:] for n contiguous fp32 tensors (src[i] == NULL: zeros), pointers in kernel arguments as
+ * above: the gather of a gradient bucket into its flat all-reduce buffer -- the "flat buckets" of the reference's dormant
+ * all_reduce_and_rescale_tensors (onmt/utils/distributed.py:47-86), one launch per 96 tensors. */
+int mssr_multi_copy(int n, void* const* dst, void* const* src, const int64_t* numels, float scale, void* stream);
 
 /* ---------------------------------------------------------------- embeddings + PE ---------
  * Replaces nn.Embedding lookup + PositionalEncoding (onmt/modules/embeddings.py:48-54,282):
@@ -264,10 +268,14 @@ int mssr_scale_add_pe(const void* x, const float* pe, void* out, int64_t rows, i
  * q/k/v are [B, L, H, dh] views (head h at column offset h*dh) addressed by batch and row strides in
  * elements (multiples of 4), so the packed projection [B*L, 3d] is used in place; mask is uint8,
  * nonzero = masked, row of (b, i) at mask + b*mask_bs + i*mask_qs (mask_qs = 0: key padding only).
- * Limits: Lk <= 64, dh <= 64 (and Lq <= 64 backward), staged tiles within 64 KB of LDS --
- * mssr_attention_fits() tells; larger shapes go through mssr_gemm + mssr_softmax_*.
- * Dropout: keep(b,h,i,t) = hash(seed, ((b*H+h)*Lq + i)*64 + t) >= p_drop * 2^32, regenerated by the
- * backward from the same seed. */
+ * Two kernel families behind one entry point (mssr_attention_fits() tells whether either applies; larger shapes go
+ * through mssr_gemm + mssr_softmax_*):
+ *   matrix-core kernels (csrc/attention_mfma.hip): bf16, dh = 32 or 64, Lk <= 160 (and Lq <= 160 backward), q/k/v
+ *     rows 16-byte aligned -- the sentence lengths of every configuration incl. the 128-word stress case;
+ *   scalar kernels (csrc/attention.hip): fp32 or bf16, Lk <= 64, dh <= 64 (and Lq <= 64 backward), staged tiles
+ *     within 64 KB of LDS -- the fp32 parity runs and odd head sizes.  MSSR_ATTN_MFMA=0 prefers them where both fit.
+ * Dropout: keep(b,h,i,t) = hash16(seed, ((b*H+h)*Lq + i)*256 + t) >= p_drop * 2^16 (one 32-bit hash per key pair),
+ * the same decision in both families, regenerated by the backward from the same seed. */
 typedef struct {
     const void *q, *k, *v;
     const uint8_t* mask;          /* may be NULL */

@@ -124,6 +124,7 @@ SIGNATURES = {
     "mssr_adam_step": ([_I, _P, _P, _P, _P, _P, _P, _P, _F, _F, _F, _F, _P, _I, _P], c_int),
     "mssr_pack_blocks": ([_I], c_int),
     "mssr_pack_weights": ([_P, _I, _I, _I, _P], c_int),
+    "mssr_multi_copy": ([_I, _P, _P, _P, _F, _P], c_int),
     "mssr_embedding_fwd": ([_P, _P, _P, _P, _L, _I, _L, _L, _I, _F, _I, _P], c_int),
     "mssr_embedding_bwd": ([_P, _P, _P, _L, _I, _L, _L, _F, _I, _P], c_int),
     "mssr_scale_add_pe": ([_P, _P, _P, _L, _I, _L, _I, _F, _I, _P], c_int),

@@ -136,6 +136,22 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(const OptPack pk, float* 
     }
 }
 
+// dst[t] = scale * src[t] for tensor blockIdx.y (src null: zeros) -- the gather of a gradient bucket into its flat
+// all-reduce buffer (parallel.GradSync._fill; p = destination slices, g = the gradients)
+__global__ __launch_bounds__(256) void opt_copy_kernel(const OptPack pk, float scale) {
+    const int t = blockIdx.y;
+    const float* g = pk.g[t];
+    float* p = pk.p[t];
+    const int n = pk.n[t];
+    const int n4 = n & ~3;
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < n4; i += gridDim.x * 1024) {
+        float4 v = g ? *reinterpret_cast<const float4*>(g + i) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        *reinterpret_cast<float4*>(p + i) = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < n - n4) p[n4 + threadIdx.x] = g ? g[n4 + threadIdx.x] * scale : 0.f;
+}
+
 static int blocks_for(int64_t max_n) {
     int64_t b = (max_n + OPT_CHUNK - 1) / OPT_CHUNK;
     if (b < 1) b = 1;
@@ -219,4 +235,26 @@ extern "C" int mssr_adam_step(int n, void* const* params, void* const* grads, co
                                                                       beta2, eps, write_clipped);
     }
     MSSR_LAUNCH_OK("adam_step");
+}
+
+extern "C" int mssr_multi_copy(int n, void* const* dst, void* const* src, const int64_t* numels, float scale,
+                               void* stream) {
+    if (int e = check_list("multi_copy", n, dst, src, numels)) return e;
+    hipStream_t s = (hipStream_t)stream;
+    for (int base = 0; base < n; base += OPT_PER_LAUNCH) {
+        OptPack pk;
+        pk.count = n - base < OPT_PER_LAUNCH ? n - base : OPT_PER_LAUNCH;
+        int64_t mx = 0;
+        for (int i = 0; i < pk.count; ++i) {
+            pk.p[i] = (float*)dst[base + i];
+            pk.g[i] = (const float*)src[base + i];
+            pk.n[i] = (int)numels[base + i];
+            pk.off[i] = 0;
+            pk.lr_over_bc1[i] = pk.inv_sqrt_bc2[i] = 0.f;
+            if (numels[base + i] > mx) mx = numels[base + i];
+        }
+        if (mx == 0) continue;
+        opt_copy_kernel<<<dim3(blocks_for(mx), pk.count), 256, 0, s>>>(pk, scale);
+    }
+    MSSR_LAUNCH_OK("multi_copy");
 }

@@ -68,13 +68,16 @@ class GradSync:
                 buckets.append((cur, hooked))
         plan = []
         for ps, hooked in buckets:
-            n = sum(p.numel() for p in ps)
-            flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
-            views, off = [], 0
+            # every slice starts on a 16-byte boundary: the multi-tensor kernels (gather below, clip + Adam in optim.py)
+            # read the slices with 16-byte accesses
+            offs, n = [], 0
             for p in ps:
-                views.append(flat[off:off + p.numel()].view_as(p))
-                off += p.numel()
-            plan.append(dict(params=ps, flat=flat, views=views, ready=0, launched=False, armed=False, hooked=hooked))
+                offs.append(n)
+                n += (p.numel() + 3) // 4 * 4
+            flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
+            views = [flat[off:off + p.numel()].view_as(p) for off, p in zip(offs, ps)]
+            plan.append(dict(params=ps, flat=flat, views=views, ready=0, launched=False, armed=False, hooked=hooked,
+                             scaled=False, tables=None))
         self._plans[id(module)] = plan
         # gradient hooks are registered ONCE (registering and removing ~400 of them per phase cost ~2 ms of host
         # time per step); they only count while their bucket is armed
@@ -104,9 +107,27 @@ class GradSync:
         return self._stream
 
     def _fill(self, b):
-        """Gradients of the bucket's parameters -> its flat buffer: ONE multi-tensor copy (two kernels per
-        bucket instead of two per parameter); parameters without a gradient contribute zeros."""
-        live = [(v, p.grad) for v, p in zip(b["views"], b["params"]) if p.grad is not None]
+        """Gradients of the bucket's parameters -> its flat buffer; parameters without a gradient contribute zeros.
+        On the GPU: ONE multi-tensor launch per 96 tensors (mssr_multi_copy, pointers in the kernel arguments) that
+        also pre-divides by the world size, so the reduced sum IS the mean; elsewhere (CPU tensors under gloo) one
+        torch multi-tensor copy."""
+        grads = [p.grad for p in b["params"]]
+        if b["flat"].is_cuda and all(g is None or (g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda
+                                                   and g.data_ptr() % 16 == 0) for g in grads):
+            import ctypes
+            from . import _lib as L
+            n = len(grads)
+            if b["tables"] is None:
+                b["tables"] = ((ctypes.c_void_p * n)(*[v.data_ptr() for v in b["views"]]), (ctypes.c_void_p * n)(),
+                               (ctypes.c_int64 * n)(*[p.numel() for p in b["params"]]))
+            dst, src, numels = b["tables"]
+            for i, g in enumerate(grads):
+                src[i] = None if g is None else g.data_ptr()     # a gradient that IS its slice is scaled in place
+            L.check(L.load().mssr_multi_copy(n, dst, src, numels, 1.0 / self.world, L.stream()), "multi_copy")
+            b["scaled"] = True
+            return
+        b["scaled"] = False
+        live = [(v, g) for v, g in zip(b["views"], grads) if g is not None]
         if len(live) < len(b["params"]):
             # (a gradient that still IS its slice -- accumulation without zero_grad -- must survive the zero fill)
             keep = [(v, g.clone()) for v, g in live if g.data_ptr() == v.data_ptr()]
@@ -183,7 +204,7 @@ class GradSync:
             torch.cuda.current_stream().wait_stream(self._stream)
         inv = 1.0 / self.world
         for b, _ in self._pending:
-            if self.world > 1:
+            if self.world > 1 and not b["scaled"]:
                 b["flat"].mul_(inv)
             # No scatter back: every parameter's .grad BECOMES its slice of the reduced flat buffer (a pointer swap
             # on the host; the optimizer reads the slices in place).  The slices stay valid until this bucket is
