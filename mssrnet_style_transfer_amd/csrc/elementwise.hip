@@ -103,6 +103,68 @@ __global__ __launch_bounds__(EW_BLOCK) void axpby_kernel(const T* __restrict__ x
     }
 }
 
+// Column sums, wide form (rows 16-byte aligned, n a multiple of the vector): a lane owns one 16-byte column group
+// (8 bf16 / 4 fp32), a wave reads 1 KB of one row per instruction, four rows in flight per wave; the block's waves
+// split the rows of its slice, partial sums meet in LDS and leave as one float atomic per column and block.
+// 4480 x 1536 bf16 (bias gradients of the packed projections over all decode steps): 16 -> 6 us.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                          int n, int64_t ldx, int64_t x_bs, int64_t out_bs) {
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ float sm[4][64 * V];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = (blockIdx.x * 64 + lane) * V;
+    x += (int64_t)blockIdx.z * x_bs;
+    out += (int64_t)blockIdx.z * out_bs;
+    float acc[V];
+#pragma unroll
+    for (int u = 0; u < V; ++u) acc[u] = 0.f;
+    if (c < n) {
+        const int64_t stride = (int64_t)gridDim.y * 4;
+        int64_t r = (int64_t)blockIdx.y * 4 + wave;
+        for (; r + 3 * stride < rows; r += 4 * stride) {
+            uint4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const uint4*>(x + (r + k * stride) * ldx + c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const T* e = reinterpret_cast<const T*>(&v[k]);
+#pragma unroll
+                for (int u = 0; u < V; ++u) acc[u] += to_f(e[u]);
+            }
+        }
+        for (; r < rows; r += stride) {
+            const uint4 v = *reinterpret_cast<const uint4*>(x + r * ldx + c);
+            const T* e = reinterpret_cast<const T*>(&v);
+#pragma unroll
+            for (int u = 0; u < V; ++u) acc[u] += to_f(e[u]);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < V; ++u) sm[wave][lane * V + u] = acc[u];
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * V; i += 256) {
+        const int col = blockIdx.x * 64 * V + i;
+        if (col < n) atomicAdd(out + col, (sm[0][i] + sm[1][i]) + (sm[2][i] + sm[3][i]));
+    }
+}
+
+template <typename T>
+static bool colsum_wide_ok(const void* x, int n, int64_t ldx, int64_t x_bs) {
+    constexpr int V = 16 / (int)sizeof(T);
+    return aligned(x, 16) && n % V == 0 && ldx % V == 0 && x_bs % V == 0;
+}
+
+// row slices for the wide kernel: enough blocks to cover the chip a few times, at least 8 rows per wave
+static unsigned colsum_slices(int64_t rows, int64_t chunks, int64_t batch) {
+    int64_t gy = (rows + 31) / 32;
+    const int64_t want = (2048 + chunks * batch - 1) / (chunks * batch);
+    if (gy > want) gy = want;
+    if (gy < 1) gy = 1;
+    if (gy > 65535) gy = 65535;
+    return (unsigned)gy;
+}
+
 // Column sums: block (64 x 4): 64 consecutive columns x 4 row-lanes; rows split over gridDim.y,
 // partial results combined with float atomics (out zeroed by the host call unless accumulate).
 template <typename T>
@@ -256,6 +318,16 @@ extern "C" int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64
     hipStream_t s = (hipStream_t)stream;
     if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * n, s);
     if (rows == 0) return MSSR_OK;
+    if (dtype == MSSR_BF16 && colsum_wide_ok<bf16>(x, n, ldx, 0)) {
+        const int chunks = (n + 511) / 512;
+        colsum_wide_kernel<bf16><<<dim3(chunks, colsum_slices(rows, chunks, 1)), dim3(256), 0, s>>>((const bf16*)x, out, rows, n, ldx, 0, 0);
+        MSSR_LAUNCH_OK("colsum");
+    }
+    if (dtype == MSSR_F32 && colsum_wide_ok<float>(x, n, ldx, 0)) {
+        const int chunks = (n + 255) / 256;
+        colsum_wide_kernel<float><<<dim3(chunks, colsum_slices(rows, chunks, 1)), dim3(256), 0, s>>>((const float*)x, out, rows, n, ldx, 0, 0);
+        MSSR_LAUNCH_OK("colsum");
+    }
     int64_t gy = (rows + 63) / 64;
     if (gy > 64) gy = 64;
     const dim3 grid((n + 63) / 64, (unsigned)gy);
@@ -275,6 +347,18 @@ extern "C" int mssr_colsum_batched(const void* x, float* out, int batch, int64_t
     hipStream_t s = (hipStream_t)stream;
     (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * batch, s);
     if (rows == 0) return MSSR_OK;
+    if (dtype == MSSR_BF16 && colsum_wide_ok<bf16>(x, n, ldx, x_bs)) {
+        const int chunks = (n + 511) / 512;
+        colsum_wide_kernel<bf16><<<dim3(chunks, colsum_slices(rows, chunks, batch), batch), dim3(256), 0, s>>>(
+            (const bf16*)x, out, rows, n, ldx, x_bs, n);
+        MSSR_LAUNCH_OK("colsum_batched");
+    }
+    if (dtype == MSSR_F32 && colsum_wide_ok<float>(x, n, ldx, x_bs)) {
+        const int chunks = (n + 255) / 256;
+        colsum_wide_kernel<float><<<dim3(chunks, colsum_slices(rows, chunks, batch), batch), dim3(256), 0, s>>>(
+            (const float*)x, out, rows, n, ldx, x_bs, n);
+        MSSR_LAUNCH_OK("colsum_batched");
+    }
     int64_t gy = (rows + 63) / 64;
     if (gy > 64) gy = 64;
     const dim3 grid((n + 63) / 64, (unsigned)gy, (unsigned)batch);

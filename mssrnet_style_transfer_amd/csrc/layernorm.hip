@@ -3,6 +3,7 @@
 // 8-B accesses), two-pass mean/variance by wave shuffles.  HBM-bound by design:
 // fwd moves 2*rows*d elements, bwd 3*rows*d, bwd_bwd 5*rows*d (+ O(d) parameters).
 #include "common.hpp"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace mssr {
@@ -300,9 +301,16 @@ template <typename F> static void dispatch_nv(int nv, F&& f) {
 using namespace mssr;
 
 extern "C" int mssr_layernorm_partial_rows(int64_t rows) {
+    static const int64_t max_parts = [] {
+        const char* e = getenv("MSSR_LN_PARTS");
+        return e ? (int64_t)atoll(e) : (int64_t)LN_MAX_PARTS;
+    }();
     int64_t b = (rows + LN_WPB - 1) / LN_WPB;
     if (b < 1) b = 1;
-    return (int)(b < LN_MAX_PARTS ? b : LN_MAX_PARTS);
+    // more slices shorten the per-wave row loop but lengthen the finalize pass: 4480 x 512 bf16 15 us with 256 slices,
+    // 20 us with 512; 71680 x 512 91 us with 256, 61 us with 512 (tools/ln_bench.py)
+    const int64_t cap = (rows > 32768 && max_parts == LN_MAX_PARTS) ? 2 * max_parts : max_parts;
+    return (int)(b < cap ? b : cap);
 }
 
 extern "C" int mssr_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* mean,

@@ -825,3 +825,25 @@ def test_adam_and_global_norm_clip_match_torch():
     n1 = opt.grad_norm(1.0).clone()
     n2 = opt.grad_norm(1.0).clone()
     assert torch.equal(n1, n2)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("rows,n,ld", [(4480, 1536, 1536), (1, 512, 512), (37, 520, 528), (1000, 9606, 9606), (333, 50, 50),
+                                       (70000, 512, 1536)])
+def test_colsum_matches_torch(ops, dtype, rows, n, ld):
+    """Bias gradients = column sums over all (step, sentence) rows: the 16-byte wide kernel (aligned shapes) and the
+    scalar kernel (ragged widths such as V = 9606), plain and batched over layers, against float64."""
+    from mssrnet_style_transfer_amd import _lib
+    from mssrnet_style_transfer_amd.decode_engine import _bsum, _colsum
+    torch.manual_seed(rows + n)
+    x = torch.randn(rows, ld, device="cuda").to(dtype)
+    view = x[:, :n]
+    want = view.double().sum(0).float()
+    tol = 1e-5 if dtype == torch.float32 else 1e-5            # fp32 accumulation of exactly representable inputs
+    got = _colsum(view)
+    assert_close(got, want, tol, "colsum", floor=1e-3 * rows ** 0.5 * 1e-2)
+    if rows <= 5000:
+        xb = torch.randn(3, rows, ld, device="cuda").to(dtype)
+        gb = _bsum(xb[:, :, :n])
+        assert_close(gb, xb[:, :, :n].double().sum(1).float(), tol, "colsum batched", floor=1e-3 * rows ** 0.5 * 1e-2)
+    assert _lib.load() is not None
