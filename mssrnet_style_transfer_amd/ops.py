@@ -299,7 +299,7 @@ def _long_k_nn(a, w, out_dtype):
     ap[:, :K].copy_(a.detach())
     if kp > K:
         ap[:, K:].zero_()
-    return gemm(ap, wt, True, out_dtype)
+    return gemm(ap, wt, True, out_dtype), ap
 
 
 class _Matmul(Function):
@@ -310,9 +310,13 @@ class _Matmul(Function):
         ctx.cd = _state["dtype"]
         ctx.save_for_backward(a, b)
         ctx.tb = tb
+        ctx.a_pad = None
         if (not tb and not heads_last and a.dim() == 2 and b.dim() == 2 and isinstance(b, torch.nn.Parameter)
                 and b.shape[0] > 2048 and _state["dtype"] == torch.bfloat16 and a.is_cuda):
-            return _long_k_nn(a, b, out_dtype or _state["dtype"])
+            out, ap = _long_k_nn(a, b, out_dtype or _state["dtype"])
+            if b.requires_grad:
+                ctx.a_pad = ap          # the weight gradient a^T dc reads this bf16 copy (rows padded to 16 bytes)
+            return out
         if (not tb and not heads_last and a.dim() == 2 and b.dim() == 2 and isinstance(b, torch.nn.Parameter)
                 and a.is_cuda):
             wt = transposed(b)
@@ -344,6 +348,12 @@ class _Matmul(Function):
         if ctx.needs_input_grad[1]:
             if ctx.tb:
                 db = _Matmul.apply(dc.transpose(-1, -2), a, False, b.dtype)
+            elif ctx.a_pad is not None and not (torch.is_grad_enabled() and a.requires_grad):
+                # vocabulary-wide weight gradient (soft embedding: table gradient = probabilities^T dc) on the padded
+                # bf16 copy the forward made: no second cast of the [rows, V] operand, and its 16-byte aligned rows
+                # take the LDS-DMA kernel (9606 x 256 x 2880: 144 -> ~50 us)
+                ap = ctx.a_pad
+                db = gemm(ap[:, :a.shape[1]].t(), cast(dc).contiguous(), False, b.dtype)
             else:
                 db = _Matmul.apply(a.transpose(-1, -2), dc, False, b.dtype)
         return da, db, None, None, None
