@@ -460,6 +460,50 @@ int mssr_decode_step_bwd(const mssr_decode_plan* plan, int step, void* stream);
 int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);
 int mssr_decode_bwd(const mssr_decode_plan* plan, void* stream);
 
+/* ------------------------------------------------ teacher-forced decoder-stack engine ------
+ * Replaces the Python layer loop of TransformerDecoder.forward with step = None
+ * (onmt/decoders/transformer.py:289-337) -> n_layers x TransformerDecoderLayer._forward (:110-171) -> final
+ * LayerNorm (:331), and its autograd backward: the whole target sequence at once (the reconstruction phase's decoder
+ * pass, onmt/trainer_wgan_wh.py:632-664).  Rows are batch-first, R = B*T; the caller embeds the target into X[0],
+ * projects the memory bank onto every layer's context keys | values with ONE product (mem_kv [B*Ls, n_layers*2d],
+ * layer l at columns [l*2d, (l+1)*2d)) and owns every buffer.  `layers` (a HOST array) is the step-wise engine's
+ * mssr_dec_layer: both engines read the same weight pack.  Dropout as in the encoder engine (regenerated from the
+ * seed by the backward). */
+typedef struct {
+    int dtype;
+    int B, T, Ls, d, heads, ff, n_layers;
+    int save;                     /* 1: keep per-layer activations for mssr_decstack_bwd */
+    int training;                 /* 1: dropout active */
+    float p_drop, p_attn;
+    uint64_t seed;
+    const mssr_dec_layer* layers;
+    const float *lnF_g, *lnF_b;   /* TransformerDecoder.layer_norm */
+    const uint8_t* self_mask;     /* [B, T, T] nonzero = masked: causal | target padding (:132-149) */
+    const uint8_t* src_mask;      /* [B, Ls]  nonzero = padding key of the memory bank, or NULL */
+    void* X;                      /* [n_layers+1][R, d]; X[0] = embedded target rows (input) */
+    void* out;                    /* [R, d] final LayerNorm output */
+    const void* mem_kv;           /* [B*Ls, n_layers*2d] */
+    void* probs;                  /* [B, heads, T, Ls] context-attention probabilities of the LAST layer, or NULL */
+    void* qkv;                    /* [n_layers][R, 3d] (one slot when save = 0) */
+    void* actD;                   /* [n_layers][8][R, d]: n1 | ctx_self | h1 | n2 | ctx_query | ctx_ctx | h2 | n3 */
+    void* actF;                   /* [n_layers][R, ff] */
+    float* stats;                 /* [3*n_layers+1][2][R]  mean | rstd of every LayerNorm */
+    void* gemm_ws;
+    int64_t gemm_ws_bytes;
+    /* backward */
+    const void* dout;             /* [R, d] gradient of `out` */
+    void* dX;                     /* [R, d] gradient of X[0] (output) */
+    void* dqkv;                   /* [n_layers][R, 3d] */
+    void* dactD;                  /* [n_layers][7][R, d]: dn1 | d_so | dn2 | d_cq | d_co | dn3 | d_f2 (gradients of the outputs
+                                   * of layer_norm_1, self final_linear, layer_norm_2, context linear_query, context
+                                   * final_linear, feed_forward.layer_norm, w_2) */
+    void* dactF;                  /* [n_layers][R, ff] gradient of the w_1 output */
+    void* dctx;                   /* [R, d] scratch */
+    void* dmem_kv;                /* [B*Ls, n_layers*2d] gradient of mem_kv (every column block written once) */
+} mssr_decstack_plan;
+int mssr_decstack_fwd(const mssr_decstack_plan* plan, void* stream);
+int mssr_decstack_bwd(const mssr_decstack_plan* plan, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

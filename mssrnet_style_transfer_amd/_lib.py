@@ -74,6 +74,16 @@ class DecodePlan(Structure):
                 + [("greedy", c_int), ("eval_rows", c_int), ("bwd_row0", c_int)])
 
 
+class DecStackPlan(Structure):
+    """mssr_decstack_plan (include/mssr_hip.h)."""
+    _fields_ = ([(n, c_int) for n in ("dtype", "B", "T", "Ls", "d", "heads", "ff", "n_layers", "save", "training")]
+                + [("p_drop", c_float), ("p_attn", c_float), ("seed", c_uint64), ("layers", POINTER(DecLayer))]
+                + [(n, c_void_p) for n in ("lnF_g", "lnF_b", "self_mask", "src_mask", "X", "out", "mem_kv", "probs", "qkv",
+                                           "actD", "actF", "stats", "gemm_ws")]
+                + [("gemm_ws_bytes", c_int64)]
+                + [(n, c_void_p) for n in ("dout", "dX", "dqkv", "dactD", "dactF", "dctx", "dmem_kv")])
+
+
 class AttnDesc(Structure):
     """mssr_attn_desc (include/mssr_hip.h)."""
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("mask", c_void_p),
@@ -136,6 +146,8 @@ SIGNATURES = {
     "mssr_prof_get": ([_I, POINTER(ProfRecord)], c_int),
     "mssr_encoder_fwd": ([POINTER(EncoderPlan), _P], c_int),
     "mssr_encoder_bwd": ([POINTER(EncoderPlan), _P], c_int),
+    "mssr_decstack_fwd": ([POINTER(DecStackPlan), _P], c_int),
+    "mssr_decstack_bwd": ([POINTER(DecStackPlan), _P], c_int),
     "mssr_decode_step_fwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_step_bwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_fwd": ([POINTER(DecodePlan), _P], c_int),

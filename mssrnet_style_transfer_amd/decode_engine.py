@@ -61,16 +61,23 @@ class _Pack:
     buffers are allocated once; ``refresh()`` recomputes all of them from the fp32 parameters in one launch
     (weight_pack.JobTable -> csrc/pack.hip)."""
 
-    def __init__(self, params, n_layers, cd):
-        E, lnFg, lnFb, Wg, bg = params[:N_HEAD_PARAMS]
-        lp = [params[N_HEAD_PARAMS + i * N_LAYER_PARAMS: N_HEAD_PARAMS + (i + 1) * N_LAYER_PARAMS]
-              for i in range(n_layers)]
+    def __init__(self, params, n_layers, cd, head=True):
+        """``head`` = False: params = [lnF_g, lnF_b] + the layers' 26 each -- the decoder alone, without the embedding
+        table and the generator (decoder_stack.py, when no model has claimed the decoder yet)."""
+        if head:
+            E, lnFg, lnFb, Wg, bg = params[:N_HEAD_PARAMS]
+            first = N_HEAD_PARAMS
+        else:
+            (lnFg, lnFb), first = params[:2], 2
+            E = Wg = bg = None
+        lp = [params[first + i * N_LAYER_PARAMS: first + (i + 1) * N_LAYER_PARAMS] for i in range(n_layers)]
         NL = n_layers
-        V, d = E.shape
+        d = lp[0][_WQ].shape[1]
+        V = E.shape[0] if head else 0
         ff = lp[0][_W1].shape[0]
         Vp = (V + 31) // 32 * 32
-        dev = E.device
-        self.NL, self.V, self.Vp, self.d, self.ff, self.cd = NL, V, Vp, d, ff, cd
+        dev = lnFg.device
+        self.NL, self.V, self.Vp, self.d, self.ff, self.cd, self.head = NL, V, Vp, d, ff, cd, head
         e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
         f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)  # noqa: E731
         for name, n_out, n_in in (("qkv", 3 * d, d), ("so", d, d), ("cq", d, d), ("co", d, d), ("1", ff, d), ("2", d, ff)):
@@ -81,10 +88,12 @@ class _Pack:
         self.wt_ckv = e(NL, d, 2 * d)
         for name in ("ln1_g", "ln1_b", "ln2_g", "ln2_b", "lnf_g", "lnf_b"):
             setattr(self, name, f(NL, d))
-        self.emb, self.w_gen = e(V, d), e(V, d)
-        self.emb_t = torch.zeros(d, Vp, dtype=cd, device=dev)              # columns V..Vp stay zero
-        self.wt_gen = torch.zeros(d, Vp, dtype=cd, device=dev)
-        self.b_gen, self.lnF_g, self.lnF_b = f(V), f(d), f(d)
+        if head:
+            self.emb, self.w_gen = e(V, d), e(V, d)
+            self.emb_t = torch.zeros(d, Vp, dtype=cd, device=dev)          # columns V..Vp stay zero
+            self.wt_gen = torch.zeros(d, Vp, dtype=cd, device=dev)
+            self.b_gen = f(V)
+        self.lnF_g, self.lnF_b = f(d), f(d)
         # LayerNorm folded into the Linear behind it (bf16 skinny kernel, mssr_gemm_desc.ln_colsum):
         # W' = gamma * W (rounded to bf16), colsum(W') of the ROUNDED values, bias' = W beta + b
         self.fuse_ln = cd == torch.bfloat16 and d % 32 == 0 and d <= 2048
@@ -96,7 +105,8 @@ class _Pack:
                 setattr(self, "wg_" + name, e(NL, n_out, d))
                 setattr(self, "cs_" + name, f(NL, n_out))
                 setattr(self, "bf_" + name, f(NL, n_out))
-            self.wg_gen, self.cs_gen, self.bf_gen = e(V, d), f(V), f(V)
+            if head:
+                self.wg_gen, self.cs_gen, self.bf_gen = e(V, d), f(V), f(V)
             names += ["wg_qkv", "wg_cq", "wg_1", "cs_qkv", "cs_cq", "cs_1", "bf_qkv", "bf_cq", "bf_1"]
 
         jt = self.jobs = JobTable(cd, dev)
@@ -129,12 +139,13 @@ class _Pack:
             for name, idx in (("ln1_g", _LN1G), ("ln1_b", _LN1B), ("ln2_g", _LN2G), ("ln2_b", _LN2B), ("lnf_g", _LNFG),
                               ("lnf_b", _LNFB)):
                 jt.add(lp[l][idx], dst_f=getattr(self, name)[l])
-        jt.add(E, dst=self.emb, dst_t=self.emb_t[:, :V])
-        kw = {}
-        if self.fuse_ln:
-            kw = dict(dst_g=self.wg_gen, gamma=lnFg, beta=lnFb, bias=bg, colsum=self.cs_gen, bias_f=self.bf_gen)
-        jt.add(Wg, dst=self.w_gen, dst_t=self.wt_gen[:, :V], **kw)
-        jt.add(bg, dst_f=self.b_gen)
+        if head:
+            jt.add(E, dst=self.emb, dst_t=self.emb_t[:, :V])
+            kw = {}
+            if self.fuse_ln:
+                kw = dict(dst_g=self.wg_gen, gamma=lnFg, beta=lnFb, bias=bg, colsum=self.cs_gen, bias_f=self.bf_gen)
+            jt.add(Wg, dst=self.w_gen, dst_t=self.wt_gen[:, :V], **kw)
+            jt.add(bg, dst_f=self.b_gen)
         jt.add(lnFg, dst_f=self.lnF_g)
         jt.add(lnFb, dst_f=self.lnF_b)
         jt.finish()
@@ -207,11 +218,22 @@ def cached_pack(cache, owner, params, build):
     return pack
 
 
+_decoder_owner = weakref.WeakValueDictionary()      # id(decoder) -> the model whose pack covers it
+
+
 def get_pack(model, params):
     """The packed weights of ``model``'s decoder, rebuilt when any parameter changed in place."""
     cd = ops.compute_dtype()
+    _decoder_owner[id(model.decoder)] = model
     return cached_pack(_pack_cache, model, params,
                        lambda: _Pack(params, len(model.decoder.transformer_layers), cd))
+
+
+def model_of(decoder):
+    """The model that ran a soft / greedy decode with this decoder (its pack already holds every layer's weights), or
+    None."""
+    m = _decoder_owner.get(id(decoder))
+    return m if m is not None and getattr(m, "decoder", None) is decoder else None
 
 
 def clear_pack_cache():

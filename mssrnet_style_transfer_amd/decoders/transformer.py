@@ -22,6 +22,7 @@ from .. import ops
 from ..modules.multi_headed_attn import MultiHeadedAttention
 from ..modules.position_ffn import PositionwiseFeedForward
 from ..utils.misc import sequence_mask
+from ..decoder_stack import run_stack
 from .decoder import DecoderBase
 
 _CACHE_SLOTS = ("memory_keys", "memory_values", "self_keys", "self_values")
@@ -157,6 +158,13 @@ class TransformerDecoder(DecoderBase):
         # reproduces the reference (:294,306), i.e. effectively no target padding mask on that path
         tgt_pad = tgt[:, :, 0].t().detach().eq(self.embeddings.word_padding_idx).unsqueeze(1)
         caches = self.state["cache"] if step is not None else None
+        if step is None and len(self.transformer_layers) > 0:
+            # the whole target sequence at once: all layers + final LayerNorm as one engine call per direction
+            layer0 = self.transformer_layers[0]
+            fused = run_stack(self, x, memory, layer0._self_mask(tgt_pad, None), src_pad[:, 0])
+            if fused is not None:
+                dec_outs, top = fused
+                return dec_outs.transpose(0, 1).contiguous(), {"std": top.transpose(0, 1).contiguous()}
         top = None
         for i, layer in enumerate(self.transformer_layers):
             x, top, _ = layer(x, memory, src_pad, tgt_pad, step=step,
