@@ -52,6 +52,14 @@ int mssr_layernorm_bwd_bwd(const void* ggx, const float* ggg, const float* ggb, 
                            const void* x, const float* gamma, const float* mean, const float* rstd,
                            void* g_dy, void* g_x, float* g_gamma, float* partial, int64_t rows,
                            int d, int dtype, void* stream);
+/* dgamma / dbeta alone, batched: out[z][0][:] = sum_rows dy*xhat, out[z][1][:] = sum_rows dy for z < batch, operand z at
+ * base + z*stride (strides in elements; out_bs >= 2d floats).  What the engines need after their backward sweeps (which
+ * produce dx themselves): one launch per LayerNorm KIND over all layers (onmt/decoders/transformer.py:69-70,244,
+ * onmt/encoders/transformer.py:34,101, onmt/modules/position_ffn.py:20 -- autograd's weight / bias gradients of nn.LayerNorm).
+ * d a multiple of 8 (bf16) / 4 (fp32), operands 16-byte aligned. */
+int mssr_layernorm_param_grads(const void* dy, const void* x, const float* mean, const float* rstd, float* out, int batch,
+                               int64_t dy_bs, int64_t x_bs, int64_t stat_bs, int64_t out_bs, int64_t rows, int d,
+                               int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- dense GEMM -----
  * C[z] = epilogue(alpha * A[z] . B[z]) for z in [0, batch_outer*batch_inner).

@@ -115,6 +115,7 @@ SIGNATURES = {
     "mssr_layernorm_partial_rows": ([_L], c_int),
     "mssr_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
     "mssr_layernorm_bwd_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
+    "mssr_layernorm_param_grads": ([_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _P], c_int),
     "mssr_gemm": ([POINTER(GemmDesc), _P], c_int),
     "mssr_gemm_noalloc": ([POINTER(GemmDesc), _P], c_int),
     "mssr_gemm_noalloc_scratch_bytes": ([], c_int64),

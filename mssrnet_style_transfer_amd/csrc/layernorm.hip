@@ -139,6 +139,76 @@ __global__ __launch_bounds__(LN_BLOCK) void ln_bwd_kernel(const T* __restrict__ 
     for (int i = threadIdx.x; i < 2 * d; i += LN_BLOCK) out[i] = smem[i];
 }
 
+// LayerNorm PARAMETER gradients alone, batched over layers: out[z][0][c] = sum_rows dy * xhat, out[z][1][c] = sum_rows dy
+// for slab z = blockIdx.z of every operand (element strides *_bs).  The engines need no dx here (their backward sweeps
+// produced it) and call this once per LayerNorm KIND over all layers instead of ln_bwd_kernel + ln_finalize_kernel
+// once per LayerNorm (37 x 2 launches per decoder backward).  A lane owns one 16-byte column group, a wave one row per
+// instruction; partial sums meet in LDS and leave as float atomics (out zeroed by the host call).
+template <typename T>
+__global__ __launch_bounds__(256) void ln_param_grad_kernel(const T* __restrict__ dy, const T* __restrict__ x,
+                                                            const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                            float* __restrict__ out, int64_t dy_bs, int64_t x_bs,
+                                                            int64_t stat_bs, int64_t out_bs, int64_t rows, int d) {
+    constexpr int V = 16 / (int)sizeof(T);
+    __shared__ float sm[4][2][64 * V];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    dy += (int64_t)blockIdx.z * dy_bs;
+    x += (int64_t)blockIdx.z * x_bs;
+    mean += (int64_t)blockIdx.z * stat_bs;
+    rstd += (int64_t)blockIdx.z * stat_bs;
+    out += (int64_t)blockIdx.z * out_bs;
+    const int64_t stride = (int64_t)gridDim.y * 4;
+    for (int c0 = blockIdx.x * 64 * V; c0 < d; c0 += gridDim.x * 64 * V) {
+        const int c = c0 + lane * V;
+        float ag[V], ab[V];
+#pragma unroll
+        for (int u = 0; u < V; ++u) ag[u] = ab[u] = 0.f;
+        if (c < d) {
+            int64_t r = (int64_t)blockIdx.y * 4 + wave;
+            for (; r + stride < rows; r += 2 * stride) {
+                const uint4 dv0 = *reinterpret_cast<const uint4*>(dy + r * d + c);
+                const uint4 xv0 = *reinterpret_cast<const uint4*>(x + r * d + c);
+                const uint4 dv1 = *reinterpret_cast<const uint4*>(dy + (r + stride) * d + c);
+                const uint4 xv1 = *reinterpret_cast<const uint4*>(x + (r + stride) * d + c);
+                const float mu0 = mean[r], rs0 = rstd[r], mu1 = mean[r + stride], rs1 = rstd[r + stride];
+                const T *de0 = reinterpret_cast<const T*>(&dv0), *xe0 = reinterpret_cast<const T*>(&xv0);
+                const T *de1 = reinterpret_cast<const T*>(&dv1), *xe1 = reinterpret_cast<const T*>(&xv1);
+#pragma unroll
+                for (int u = 0; u < V; ++u) {
+                    const float g0 = to_f(de0[u]), g1 = to_f(de1[u]);
+                    ag[u] += g0 * ((to_f(xe0[u]) - mu0) * rs0) + g1 * ((to_f(xe1[u]) - mu1) * rs1);
+                    ab[u] += g0 + g1;
+                }
+            }
+            for (; r < rows; r += stride) {
+                const uint4 dv = *reinterpret_cast<const uint4*>(dy + r * d + c);
+                const uint4 xv = *reinterpret_cast<const uint4*>(x + r * d + c);
+                const float mu = mean[r], rs = rstd[r];
+                const T *de = reinterpret_cast<const T*>(&dv), *xe = reinterpret_cast<const T*>(&xv);
+#pragma unroll
+                for (int u = 0; u < V; ++u) {
+                    const float g = to_f(de[u]);
+                    ag[u] += g * ((to_f(xe[u]) - mu) * rs);
+                    ab[u] += g;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < V; ++u) {
+            sm[wave][0][lane * V + u] = ag[u];
+            sm[wave][1][lane * V + u] = ab[u];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < 2 * 64 * V; i += 256) {
+            const int which = i / (64 * V), j = i - which * 64 * V;
+            if (c0 + j < d)
+                atomicAdd(out + (int64_t)which * d + c0 + j,
+                          (sm[0][which][j] + sm[1][which][j]) + (sm[2][which][j] + sm[3][which][j]));
+        }
+    }
+}
+
 // sums `parts` rows of width `w` and scatters columns [0,d) to out0, [d,2d) to out1.
 // 16 columns x 16 part-groups per block: every thread has its (<= 16) loads in flight at once, so the
 // reduction is one memory round trip instead of a `parts`-long dependent chain.
@@ -396,4 +466,36 @@ extern "C" int mssr_layernorm_bwd_bwd(const void* ggx, const float* ggg, const f
     });
     ln_finalize_kernel<<<dim3((d + 15) / 16), dim3(256), 0, s>>>(partial, g_gamma, g_gamma, parts, d, d);
     MSSR_LAUNCH_OK("layernorm_bwd_bwd");
+}
+
+extern "C" int mssr_layernorm_param_grads(const void* dy, const void* x, const float* mean, const float* rstd, float* out,
+                                          int batch, int64_t dy_bs, int64_t x_bs, int64_t stat_bs, int64_t out_bs,
+                                          int64_t rows, int d, int dtype, void* stream) {
+    MSSR_REQUIRE(valid_dtype(dtype), "layernorm_param_grads: bad dtype");
+    const int v = dtype == MSSR_BF16 ? 8 : 4;
+    MSSR_REQUIRE(batch > 0 && batch <= 65535 && rows >= 0 && d > 0 && d % v == 0, "layernorm_param_grads: bad shape");
+    MSSR_REQUIRE(out && out_bs >= 2 * (int64_t)d, "layernorm_param_grads: null / overlapping output");
+    hipStream_t s = (hipStream_t)stream;
+    if (out_bs == 2 * (int64_t)d) {
+        (void)hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)d * (size_t)batch, s);
+    } else {
+        for (int z = 0; z < batch; ++z) (void)hipMemsetAsync(out + (int64_t)z * out_bs, 0, sizeof(float) * 2 * (size_t)d, s);
+    }
+    if (rows == 0) return MSSR_OK;
+    MSSR_REQUIRE(dy && x && mean && rstd, "layernorm_param_grads: null pointer");
+    MSSR_REQUIRE(aligned(dy, 16) && aligned(x, 16) && dy_bs % v == 0 && x_bs % v == 0,
+                 "layernorm_param_grads: operands must be 16-byte aligned");
+    const int chunks = (d + 64 * v - 1) / (64 * v);
+    int64_t gy = (rows + 31) / 32;
+    const int64_t want = (2048 + (int64_t)chunks * batch - 1) / ((int64_t)chunks * batch);
+    if (gy > want) gy = want;
+    if (gy < 1) gy = 1;
+    const dim3 grid((unsigned)chunks, (unsigned)gy, (unsigned)batch);
+    if (dtype == MSSR_F32)
+        ln_param_grad_kernel<float><<<grid, 256, 0, s>>>((const float*)dy, (const float*)x, mean, rstd, out, dy_bs, x_bs,
+                                                         stat_bs, out_bs, rows, d);
+    else
+        ln_param_grad_kernel<bf16><<<grid, 256, 0, s>>>((const bf16*)dy, (const bf16*)x, mean, rstd, out, dy_bs, x_bs,
+                                                        stat_bs, out_bs, rows, d);
+    MSSR_LAUNCH_OK("layernorm_param_grads");
 }

@@ -268,6 +268,25 @@ def _bsum(dy):
     return out
 
 
+def _ln_param_grads(dy, x, mean, rstd, out):
+    """LayerNorm weight / bias gradients of one LayerNorm KIND over all layers in one launch: dy, x [NL, R, d] views
+    (rows contiguous, any layer stride), mean / rstd [NL, R] views of the statistics, out [NL, 2, d] float view
+    (gamma | beta gradients).  2-D operands are one layer."""
+    if dy.dim() == 2:
+        dy, x, mean, rstd, out = dy[None], x[None], mean[None], rstd[None], out[None]
+    NL, R, d = dy.shape
+    ok = (dy.stride(2) == 1 and dy.stride(1) == d and x.stride(2) == 1 and x.stride(1) == d and mean.stride(1) == 1
+          and rstd.stride(1) == 1 and out.stride(2) == 1 and out.stride(1) == d and x.dtype == dy.dtype)
+    if NL > 1:
+        ok = ok and mean.stride(0) == rstd.stride(0)
+    if not ok:
+        raise ValueError("ln_param_grads: operands must be row-contiguous slabs with a common layer stride")
+    L.check(L.load().mssr_layernorm_param_grads(
+        dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), out.data_ptr(), NL,
+        dy.stride(0) if NL > 1 else 0, x.stride(0) if NL > 1 else 0, mean.stride(0) if NL > 1 else 0,
+        out.stride(0) if NL > 1 else 2 * d, R, d, L.dt(dy), L.stream()), "layernorm_param_grads")
+
+
 def _colsum(x):
     """float column sums of a [rows, n] matrix (row stride allowed)."""
     out = torch.empty(x.shape[1], dtype=torch.float32, device=x.device)
@@ -408,23 +427,15 @@ class _SoftDecode(Function):
                 g_mem[E0:] = gm
             else:
                 g_mem = gm
-        # LayerNorm gains / biases: sum over all (step, sentence) rows
-        parts = lib.mssr_layernorm_partial_rows(R)
-        ws = e(2 * parts * d, dtype=torch.float32)
-        scratch = e(R, d)
+        # LayerNorm gains / biases: sums over all (step, sentence) rows, one launch per LayerNorm kind over all layers
+        # (+ the final one)
         ln_g = e(3 * NL + 1, 2, d, dtype=torch.float32)
-
-        def ln_grad(idx, dy, x, gamma):
-            L.check(lib.mssr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[idx, 0].data_ptr(),
-                                           stats[idx, 1].data_ptr(), scratch.data_ptr(), ln_g[idx, 0].data_ptr(),
-                                           ln_g[idx, 1].data_ptr(), ws.data_ptr(), R, d, plan.dtype, L.stream()),
-                    "layernorm_bwd")
-
-        for l in range(NL):
-            ln_grad(3 * l + 0, dactD[l, G_DN1], X[l], pk.ln1_g[l])
-            ln_grad(3 * l + 1, dactD[l, G_DN2], actD[l, K_H1], pk.ln2_g[l])
-            ln_grad(3 * l + 2, dactD[l, G_DN3], actD[l, K_H2], pk.lnf_g[l])
-        ln_grad(3 * NL, g["dnf"], X[NL], pk.lnF_g)
+        st = stats[:3 * NL].view(NL, 3, 2, -1)
+        lg = ln_g[:3 * NL].view(NL, 3, 2, d)
+        _ln_param_grads(dactD[:, G_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0])
+        _ln_param_grads(dactD[:, G_DN2], actD[:, K_H1], st[:, 1, 0], st[:, 1, 1], lg[:, 1])
+        _ln_param_grads(dactD[:, G_DN3], actD[:, K_H2], st[:, 2, 0], st[:, 2, 1], lg[:, 2])
+        _ln_param_grads(g["dnf"], X[NL], stats[3 * NL, 0], stats[3 * NL, 1], ln_g[3 * NL])
         # generator and (soft) embedding table
         dlg = g["dlogits"][:, :V]
         gW_gen = _bgemm_t(dlg, bufs["nf"], seg)

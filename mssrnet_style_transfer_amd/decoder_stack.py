@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib as L
 from . import decode_engine as DE
 from . import ops
-from .decode_engine import _bgemm_t, _bsum, _colsum, cached_pack
+from .decode_engine import _bgemm_t, _bsum, _colsum, _ln_param_grads, cached_pack
 
 S_N1, S_CTXS, S_H1, S_N2, S_CQ, S_CTXC, S_H2, S_N3 = range(8)
 SG_DN1, SG_DOS, SG_DN2, SG_DCQ, SG_DOC, SG_DN3, SG_DF2 = range(7)
@@ -125,23 +125,15 @@ class _DecoderStack(Function):
         dmem = None
         if ctx.needs_input_grad[2]:
             dmem = ops.gemm(dmem_kv, pk.w_ckv, False, cd).view(B, Ls, d).to(ctx.dtypes[1])
+        # LayerNorm gains / biases: one launch per LayerNorm kind over all layers (+ the final one)
         stats = bufs["stats"]
-        parts = lib.mssr_layernorm_partial_rows(R)
-        ws = e(2 * parts * d, dtype=torch.float32)
-        scratch = e(R, d)
         ln_g = e(3 * NL + 1, 2, d, dtype=torch.float32)
-
-        def ln_grad(idx, dy, x, gamma):
-            L.check(lib.mssr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[idx, 0].data_ptr(),
-                                           stats[idx, 1].data_ptr(), scratch.data_ptr(), ln_g[idx, 0].data_ptr(),
-                                           ln_g[idx, 1].data_ptr(), ws.data_ptr(), R, d, plan.dtype, L.stream()),
-                    "layernorm_bwd")
-
-        for l in range(NL):
-            ln_grad(3 * l, dactD[l, SG_DN1], X[l], pk.ln1_g[l])
-            ln_grad(3 * l + 1, dactD[l, SG_DN2], actD[l, S_H1], pk.ln2_g[l])
-            ln_grad(3 * l + 2, dactD[l, SG_DN3], actD[l, S_H2], pk.lnf_g[l])
-        ln_grad(3 * NL, doutc, X[NL], pk.lnF_g)
+        st = stats[:3 * NL].view(NL, 3, 2, -1)
+        lg = ln_g[:3 * NL].view(NL, 3, 2, d)
+        _ln_param_grads(dactD[:, SG_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0])
+        _ln_param_grads(dactD[:, SG_DN2], actD[:, S_H1], st[:, 1, 0], st[:, 1, 1], lg[:, 1])
+        _ln_param_grads(dactD[:, SG_DN3], actD[:, S_H2], st[:, 2, 0], st[:, 2, 1], lg[:, 2])
+        _ln_param_grads(doutc, X[NL], stats[3 * NL, 0], stats[3 * NL, 1], ln_g[3 * NL])
         dx = g["dX"].view(B, T, d).to(ctx.dtypes[0]) if ctx.needs_input_grad[1] else None
         out = [None, dx, dmem, ln_g[3 * NL, 0], ln_g[3 * NL, 1]]
         for l in range(NL):

@@ -18,7 +18,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import ops
-from .decode_engine import _bgemm_t, _bsum, cached_pack
+from .decode_engine import _bgemm_t, _bsum, _ln_param_grads, cached_pack
 from .weight_pack import JobTable
 
 N_ENC_LAYER_PARAMS = 16
@@ -178,22 +178,14 @@ class _EncoderStack(Function):
         gW_o, gb_o = _bgemm_t(dactD[:, EG_DO], actD[:, E_CTX]), _bsum(dactD[:, EG_DO])
         gW_1, gb_1 = _bgemm_t(dactF, actD[:, E_N2]), _bsum(dactF)
         gW_2, gb_2 = _bgemm_t(dactD[:, EG_DF2], actF), _bsum(dactD[:, EG_DF2])
+        # LayerNorm gains / biases: one launch per LayerNorm kind over all layers (+ the final one)
         stats = bufs["stats"]
-        parts = lib.mssr_layernorm_partial_rows(R)
-        ws = e(2 * parts * d, dtype=torch.float32)
-        scratch = e(R, d)
         ln_g = e(2 * NL + 1, 2, d, dtype=torch.float32)
-
-        def ln_grad(idx, dy, x, gamma):
-            L.check(lib.mssr_layernorm_bwd(dy.data_ptr(), x.data_ptr(), gamma.data_ptr(), stats[idx, 0].data_ptr(),
-                                           stats[idx, 1].data_ptr(), scratch.data_ptr(), ln_g[idx, 0].data_ptr(),
-                                           ln_g[idx, 1].data_ptr(), ws.data_ptr(), R, d, plan.dtype, L.stream()),
-                    "layernorm_bwd")
-
-        for l in range(NL):
-            ln_grad(2 * l, dactD[l, EG_DN1], X[l], pk.ln1_g[l])
-            ln_grad(2 * l + 1, dactD[l, EG_DN2], actD[l, E_H], pk.lnf_g[l])
-        ln_grad(2 * NL, doutc, X[NL], pk.lnF_g)
+        st = stats[:2 * NL].view(NL, 2, 2, -1)
+        lg = ln_g[:2 * NL].view(NL, 2, 2, d)
+        _ln_param_grads(dactD[:, EG_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0])
+        _ln_param_grads(dactD[:, EG_DN2], actD[:, E_H], st[:, 1, 0], st[:, 1, 1], lg[:, 1])
+        _ln_param_grads(doutc, X[NL], stats[2 * NL, 0], stats[2 * NL, 1], ln_g[2 * NL])
         out = [None, g["dX"].view(B, Ln, d).to(ctx.x_dtype), ln_g[2 * NL, 0], ln_g[2 * NL, 1]]
         for l in range(NL):
             out += [gW_qkv[l, :d], gb_qkv[l, :d], gW_qkv[l, d:2 * d], gb_qkv[l, d:2 * d], gW_qkv[l, 2 * d:],
