@@ -125,6 +125,45 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* __restrict__
     }
 }
 
+// Vocabulary-wide rows, few of them (the decode backward: 160 rows x 9606 per step): one 1024-thread block per row --
+// sixteen waves keep a CU's memory pipe busy where the four-wave form left three quarters of the chip idle
+// (160 x 9606 fp32 probabilities and gradients -> bf16: 22 -> 9 us).
+template <typename TY, typename TD, typename TX, int NE>
+__global__ __launch_bounds__(1024) void softmax_bwd_wide_kernel(const TY* __restrict__ y, const TD* __restrict__ dy,
+                                                                TX* __restrict__ dx, int n, int64_t ldy, int64_t lddy,
+                                                                int64_t lddx, float scale, int log_mode) {
+    __shared__ float sm[16];
+    const int t = threadIdx.x;
+    const int64_t row = blockIdx.x;
+    float yv[NE], dv[NE];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = t + i * 1024;
+        if (c < n) {
+            yv[i] = to_f(y[row * ldy + c]);
+            dv[i] = to_f(dy[row * lddy + c]);
+            s += log_mode ? dv[i] : yv[i] * dv[i];
+        } else {
+            yv[i] = dv[i] = 0.f;
+        }
+    }
+    s = wave_sum(s);
+    if ((t & 63) == 0) sm[t >> 6] = s;
+    __syncthreads();
+    s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += sm[w];
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+        const int c = t + i * 1024;
+        if (c < n) {
+            const float o = log_mode ? dv[i] - expf(yv[i]) * s : yv[i] * (dv[i] - s);
+            dx[row * lddx + c] = from_f<TX>(o * scale);
+        }
+    }
+}
+
 // g_y = scale * ( g*(dy - sum(y*dy)) - dy*sum(g*y) )
 template <typename T, int G, int NE>
 __global__ __launch_bounds__(256) void softmax_bwd_bwd_kernel(const T* __restrict__ g, const T* __restrict__ y,
@@ -235,7 +274,16 @@ extern "C" int mssr_softmax_bwd(const void* y, const void* dy, void* dx, int64_t
     MSSR_REQUIRE(y && dy && dx, "softmax_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)((rows + (256 / cfg.g) - 1) / (256 / cfg.g)));
+    const bool wide = n > 4096 && rows <= 2048;     // few vocabulary-wide rows: one 1024-thread block per row
+#define SM_BWD_WIDE(TY, TD, TX, NEV)                                                                    \
+    softmax_bwd_wide_kernel<TY, TD, TX, NEV><<<dim3((unsigned)rows), dim3(1024), 0, s>>>(              \
+        (const TY*)y, (const TD*)dy, (TX*)dx, n, ldy, lddy, lddx, scale, log_mode)
 #define SM_BWD(TY, TD, TX)                                                                              \
+    if (wide) {                                                                                         \
+        if (n <= 8192) SM_BWD_WIDE(TY, TD, TX, 8);                                                      \
+        else if (n <= 10240) SM_BWD_WIDE(TY, TD, TX, 10);                                               \
+        else SM_BWD_WIDE(TY, TD, TX, 16);                                                               \
+    } else                                                                                              \
     row_dispatch(cfg, [&](auto gn) {                                                                    \
         softmax_bwd_kernel<TY, TD, TX, decltype(gn)::G, decltype(gn)::NE><<<grid, dim3(256), 0, s>>>(   \
             (const TY*)y, (const TD*)dy, (TX*)dx, rows, n, ldy, lddy, lddx, scale, log_mode);           \
@@ -252,6 +300,7 @@ extern "C" int mssr_softmax_bwd(const void* y, const void* dy, void* dx, int64_t
         default: SM_BWD(bf16, bf16, float); break;
     }
 #undef SM_BWD
+#undef SM_BWD_WIDE
     MSSR_LAUNCH_OK("softmax_bwd");
 }
 
