@@ -327,6 +327,10 @@ static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
         prof_end(pi, s, 4, d->in_dtype, d->out_dtype, 128, batch, d->m, d->n, d->k);
         MSSR_LAUNCH_OK("gemm(pipe)");
     }
+    if (!d->no_skinny && gemm_wide_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+        prof_end(pi, s, 5, d->in_dtype, d->out_dtype, 48, batch, d->m, d->n, d->k, 1, d->ln_colsum ? 1 : 0);
+        MSSR_LAUNCH_OK("gemm(wide)");
+    }
     if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {
         prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_tile(d->m, d->n, d->k), batch, d->m, d->n, d->k,
                  gemm_skinny_ksplit(d->k), d->ln_colsum ? 1 : 0);

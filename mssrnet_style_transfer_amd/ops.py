@@ -250,7 +250,9 @@ def stop_profile():
         L.check(lib.mssr_prof_get(i, ctypes.byref(r)), "prof_get")
         isz, osz = (2 if r.in_dtype == L.BF16 else 4), (2 if r.out_dtype == L.BF16 else 4)
         tin, tout = ("bf16" if isz == 2 else "f32"), ("bf16" if osz == 2 else "f32")
-        if r.kernel == 4:
+        if r.kernel == 5:
+            name = "gemm_wide_kernel<%s,%s>" % (tout, "LN" if r.ln else "noLN")
+        elif r.kernel == 4:
             name = "gemm_pipe_kernel<%s>" % tout
         elif r.kernel == 3:
             name = "gemm_lnb_kernel<%s>" % tout

@@ -847,3 +847,45 @@ def test_colsum_matches_torch(ops, dtype, rows, n, ld):
         gb = _bsum(xb[:, :, :n])
         assert_close(gb, xb[:, :, :n].double().sum(1).float(), tol, "colsum batched", floor=1e-3 * rows ** 0.5 * 1e-2)
     assert _lib.load() is not None
+
+
+@pytest.mark.parametrize("M,N,K", [(240, 9606, 512), (160, 9606, 512), (80, 2050, 256), (600, 4100, 512), (65, 9606, 256)])
+@pytest.mark.parametrize("ln", [False, True])
+def test_gemm_wide_vocabulary_kernel(ops, M, N, K, ln):
+    """The all-rows x 48-columns kernel (csrc/gemm_wide.hip) for vocabulary-wide products with few rows: generator
+    logits with the final LayerNorm folded in (bf16 out, row statistics written), and the soft embedding's input
+    gradient accumulated into an fp32 slab (beta = 1, ragged leading dimension V = 9606); against fp64."""
+    torch.manual_seed(M + N + K)
+    x = (torch.randn(M, K) * 1.3 + 0.2).bfloat16()
+    W, b = torch.randn(N, K) / math.sqrt(K), torch.randn(N)
+    ops.start_profile()
+    if ln:
+        gamma, beta = torch.rand(K) + 0.5, torch.randn(K) * 0.2
+        xd = x.double()
+        mean = xd.mean(1, keepdim=True)
+        var = xd.var(1, unbiased=False, keepdim=True)
+        ref = ((xd - mean) / (var + 1e-6).sqrt() * gamma.double() + beta.double()) @ W.double().t() + b.double()
+        wg = (W * gamma).bfloat16()
+        colsum = wg.float().sum(1).cuda()
+        bias = (W.double() @ beta.double() + b.double()).float().cuda()
+        mo, ro = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+        Np = (N + 31) // 32 * 32
+        out = torch.zeros(M, Np, device="cuda", dtype=torch.bfloat16)[:, :N]           # padded rows, as the logits slab
+        ops.gemm(x.cuda(), wg.cuda(), True, torch.bfloat16, bias=bias, ln=(colsum, mo, ro, 1e-6), out=out)
+        rec = ops.stop_profile()
+        assert_close(out.float(), ref, 2e-2, "ln-gemm wide")
+        assert_close(mo, mean.squeeze(1), 1e-4, "mean", floor=1e-5)
+        assert_close(ro, 1.0 / (var.squeeze(1) + 1e-6).sqrt(), 1e-4, "rstd")
+    else:
+        wb = W.bfloat16()
+        old = torch.randn(M, N, device="cuda")
+        out = old.clone()
+        ops.gemm(x.cuda(), wb.cuda(), True, torch.float32, out=out, beta=1.0, alpha=0.5)
+        rec = ops.stop_profile()
+        ref = 0.5 * (x.double() @ wb.double().t()) + old.double().cpu()
+        assert_close(out, ref.float(), 1e-4, "wide, fp32 accumulate", floor=1e-4)
+        ops.start_profile()
+        out2 = ops.gemm(x.cuda(), wb.cuda(), True, torch.bfloat16, bias=b.cuda())      # memory keys|values of all layers
+        rec += ops.stop_profile()
+        assert_close(out2.float(), (x.double() @ wb.double().t() + b.double()).float(), 1e-2, "wide, bias, bf16 out")
+    assert any(r["kernel"].startswith("gemm_wide_kernel") for r in rec), [r["kernel"] for r in rec]
