@@ -56,10 +56,10 @@ int mssr_layernorm_bwd_bwd(const void* ggx, const float* ggg, const float* ggb, 
  * base + z*stride (strides in elements; out_bs >= 2d floats).  What the engines need after their backward sweeps (which
  * produce dx themselves): one launch per LayerNorm KIND over all layers (onmt/decoders/transformer.py:69-70,244,
  * onmt/encoders/transformer.py:34,101, onmt/modules/position_ffn.py:20 -- autograd's weight / bias gradients of nn.LayerNorm).
- * d a multiple of 8 (bf16) / 4 (fp32), operands 16-byte aligned. */
+ * d a multiple of 8 (bf16) / 4 (fp32), operands 16-byte aligned; accumulate != 0: added to what `out` holds. */
 int mssr_layernorm_param_grads(const void* dy, const void* x, const float* mean, const float* rstd, float* out, int batch,
                                int64_t dy_bs, int64_t x_bs, int64_t stat_bs, int64_t out_bs, int64_t rows, int d,
-                               int dtype, void* stream);
+                               int accumulate, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------- dense GEMM -----
  * C[z] = epilogue(alpha * A[z] . B[z]) for z in [0, batch_outer*batch_inner).
@@ -195,9 +195,10 @@ int mssr_gate_gt0(const void* x, const void* gate, void* y, int64_t n, int dtype
 /* out[n] (+)= sum over rows of x[rows, n] (Linear bias gradient). */
 int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int accumulate,
                 int dtype, void* stream);
-/* The same for `batch` matrices x_bs elements apart (the bias gradients of all layers at once): out [batch, n]. */
+/* The same for `batch` matrices x_bs elements apart (the bias gradients of all layers at once): out [batch, n];
+ * accumulate != 0: added to what `out` holds (a caller that zeroes all its small gradient outputs with one fill). */
 int mssr_colsum_batched(const void* x, float* out, int batch, int64_t x_bs, int64_t rows, int n, int64_t ldx,
-                        int dtype, void* stream);
+                        int accumulate, int dtype, void* stream);
 /* y = a*x + b*z elementwise (z may be NULL). */
 int mssr_axpby(const void* x, const void* z, void* y, int64_t n, float a, float b, int dtype,
                void* stream);

@@ -115,7 +115,7 @@ SIGNATURES = {
     "mssr_layernorm_partial_rows": ([_L], c_int),
     "mssr_layernorm_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
     "mssr_layernorm_bwd_bwd": ([_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P], c_int),
-    "mssr_layernorm_param_grads": ([_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _P], c_int),
+    "mssr_layernorm_param_grads": ([_P, _P, _P, _P, _P, _I, _L, _L, _L, _L, _L, _I, _I, _I, _P], c_int),
     "mssr_gemm": ([POINTER(GemmDesc), _P], c_int),
     "mssr_gemm_noalloc": ([POINTER(GemmDesc), _P], c_int),
     "mssr_gemm_noalloc_scratch_bytes": ([], c_int64),
@@ -128,7 +128,7 @@ SIGNATURES = {
     "mssr_mask_scale": ([_P, _P, _P, _P, _L, _F, _I, _P], c_int),
     "mssr_gate_gt0": ([_P, _P, _P, _L, _I, _P], c_int),
     "mssr_colsum": ([_P, _P, _L, _I, _L, _I, _I, _P], c_int),
-    "mssr_colsum_batched": ([_P, _P, _I, _L, _L, _I, _L, _I, _P], c_int),
+    "mssr_colsum_batched": ([_P, _P, _I, _L, _L, _I, _L, _I, _I, _P], c_int),
     "mssr_axpby": ([_P, _P, _P, _L, _F, _F, _I, _P], c_int),
     "mssr_grad_norm_scratch_floats": ([_I], c_int64),
     "mssr_grad_norm": ([_I, _P, _P, _F, _P, _P, _P], c_int),

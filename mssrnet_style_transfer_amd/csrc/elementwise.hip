@@ -339,13 +339,13 @@ extern "C" int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64
 }
 
 extern "C" int mssr_colsum_batched(const void* x, float* out, int batch, int64_t x_bs, int64_t rows, int n, int64_t ldx,
-                                   int dtype, void* stream) {
+                                   int accumulate, int dtype, void* stream) {
     MSSR_REQUIRE(valid_dtype(dtype), "colsum_batched: bad dtype %d", dtype);
     MSSR_REQUIRE(batch > 0 && batch <= 65535 && rows >= 0 && n > 0 && ldx >= n && x_bs >= 0,
                  "colsum_batched: bad shape batch=%d rows=%lld n=%d ldx=%lld", batch, (long long)rows, n, (long long)ldx);
     MSSR_REQUIRE(out && (x || rows == 0), "colsum_batched: null pointer");
     hipStream_t s = (hipStream_t)stream;
-    (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * batch, s);
+    if (!accumulate) (void)hipMemsetAsync(out, 0, sizeof(float) * (size_t)n * batch, s);
     if (rows == 0) return MSSR_OK;
     if (dtype == MSSR_BF16 && colsum_wide_ok<bf16>(x, n, ldx, x_bs)) {
         const int chunks = (n + 511) / 512;

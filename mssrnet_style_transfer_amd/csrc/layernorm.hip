@@ -470,13 +470,15 @@ extern "C" int mssr_layernorm_bwd_bwd(const void* ggx, const float* ggg, const f
 
 extern "C" int mssr_layernorm_param_grads(const void* dy, const void* x, const float* mean, const float* rstd, float* out,
                                           int batch, int64_t dy_bs, int64_t x_bs, int64_t stat_bs, int64_t out_bs,
-                                          int64_t rows, int d, int dtype, void* stream) {
+                                          int64_t rows, int d, int accumulate, int dtype, void* stream) {
     MSSR_REQUIRE(valid_dtype(dtype), "layernorm_param_grads: bad dtype");
     const int v = dtype == MSSR_BF16 ? 8 : 4;
     MSSR_REQUIRE(batch > 0 && batch <= 65535 && rows >= 0 && d > 0 && d % v == 0, "layernorm_param_grads: bad shape");
     MSSR_REQUIRE(out && out_bs >= 2 * (int64_t)d, "layernorm_param_grads: null / overlapping output");
     hipStream_t s = (hipStream_t)stream;
-    if (out_bs == 2 * (int64_t)d) {
+    if (accumulate) {
+        // the caller zeroed `out` (one fill for all of an engine's small gradient outputs) or wants the sums added
+    } else if (out_bs == 2 * (int64_t)d) {
         (void)hipMemsetAsync(out, 0, sizeof(float) * 2 * (size_t)d * (size_t)batch, s);
     } else {
         for (int z = 0; z < batch; ++z) (void)hipMemsetAsync(out + (int64_t)z * out_bs, 0, sizeof(float) * 2 * (size_t)d, s);

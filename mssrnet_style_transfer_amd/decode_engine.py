@@ -257,21 +257,44 @@ def _bgemm_t(dy, x, seg=None):
     return ops.gemm(dy.transpose(-1, -2), x, False, torch.float32)
 
 
-def _bsum(dy):
-    """column sums of dy [NL, R, n] (bias gradients of all layers) -> float [NL, n]; one launch for all layers."""
+class _Zeros:
+    """One zero-filled fp32 arena for all the small gradient outputs of an engine backward (bias and LayerNorm
+    gradients are accumulated with float atomics into zeroed memory): one fill instead of one per output."""
+
+    def __init__(self, numel, device):
+        self.buf = torch.zeros(int(numel), dtype=torch.float32, device=device)
+        self.off = 0
+
+    def take(self, *shape):
+        n = 1
+        for v in shape:
+            n *= int(v)
+        n4 = (n + 3) // 4 * 4                       # every output starts on a 16-byte boundary
+        if self.off + n4 > self.buf.numel():
+            raise RuntimeError("gradient arena too small")
+        t = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n4
+        return t
+
+
+def _bsum(dy, out=None):
+    """column sums of dy [NL, R, n] (bias gradients of all layers) -> float [NL, n]; one launch for all layers.
+    ``out``: a ZEROED [NL, n] float view (``_Zeros.take``) to add into; None: allocated and zeroed here."""
     NL, R, n = dy.shape
     if dy.stride(-1) != 1 or dy.stride(-2) < n:
         dy = dy.contiguous()
-    out = torch.empty(NL, n, dtype=torch.float32, device=dy.device)
+    acc = out is not None
+    if out is None:
+        out = torch.empty(NL, n, dtype=torch.float32, device=dy.device)
     L.check(L.load().mssr_colsum_batched(dy.data_ptr(), out.data_ptr(), NL, dy.stride(0) if NL > 1 else 0, R, n,
-                                         dy.stride(-2), L.dt(dy), L.stream()), "colsum_batched")
+                                         dy.stride(-2), int(acc), L.dt(dy), L.stream()), "colsum_batched")
     return out
 
 
-def _ln_param_grads(dy, x, mean, rstd, out):
+def _ln_param_grads(dy, x, mean, rstd, out, zeroed=False):
     """LayerNorm weight / bias gradients of one LayerNorm KIND over all layers in one launch: dy, x [NL, R, d] views
     (rows contiguous, any layer stride), mean / rstd [NL, R] views of the statistics, out [NL, 2, d] float view
-    (gamma | beta gradients).  2-D operands are one layer."""
+    (gamma | beta gradients; ``zeroed``: it holds zeros already, no fill here).  2-D operands are one layer."""
     if dy.dim() == 2:
         dy, x, mean, rstd, out = dy[None], x[None], mean[None], rstd[None], out[None]
     NL, R, d = dy.shape
@@ -284,7 +307,7 @@ def _ln_param_grads(dy, x, mean, rstd, out):
     L.check(L.load().mssr_layernorm_param_grads(
         dy.data_ptr(), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(), out.data_ptr(), NL,
         dy.stride(0) if NL > 1 else 0, x.stride(0) if NL > 1 else 0, mean.stride(0) if NL > 1 else 0,
-        out.stride(0) if NL > 1 else 2 * d, R, d, L.dt(dy), L.stream()), "layernorm_param_grads")
+        out.stride(0) if NL > 1 else 2 * d, R, d, int(zeroed), L.dt(dy), L.stream()), "layernorm_param_grads")
 
 
 def _colsum(x):
@@ -399,12 +422,14 @@ class _SoftDecode(Function):
                 ln_fwd(actD[l, K_H1], pk.ln2_g[l], pk.ln2_b[l], actD[l, K_N2])
                 ln_fwd(actD[l, K_H2], pk.lnf_g[l], pk.lnf_b[l], actD[l, K_N3])
             ln_fwd(X[NL], pk.lnF_g, pk.lnF_b, bufs["nf"])
-        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, K_N1], seg), _bsum(dqkv)
-        gW_so, gb_so = _bgemm_t(dactD[:, G_DSO], actD[:, K_CTX1], seg), _bsum(dactD[:, G_DSO])
-        gW_cq, gb_cq = _bgemm_t(dactD[:, G_DCQ], actD[:, K_N2], seg), _bsum(dactD[:, G_DCQ])
-        gW_co, gb_co = _bgemm_t(dactD[:, G_DCO], actD[:, K_CTX2], seg), _bsum(dactD[:, G_DCO])
-        gW_1, gb_1 = _bgemm_t(dactF, actD[:, K_N3], seg), _bsum(dactF)
-        gW_2, gb_2 = _bgemm_t(dactD[:, G_DF2], actF, seg), _bsum(dactD[:, G_DF2])
+        # bias and LayerNorm gradients are float atomics into zeroed memory: ONE fill for all of them
+        zs = _Zeros(NL * (3 * d + 4 * d + ff) + (3 * NL + 1) * 2 * d + 64, dev)
+        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, K_N1], seg), _bsum(dqkv, zs.take(NL, 3 * d))
+        gW_so, gb_so = _bgemm_t(dactD[:, G_DSO], actD[:, K_CTX1], seg), _bsum(dactD[:, G_DSO], zs.take(NL, d))
+        gW_cq, gb_cq = _bgemm_t(dactD[:, G_DCQ], actD[:, K_N2], seg), _bsum(dactD[:, G_DCQ], zs.take(NL, d))
+        gW_co, gb_co = _bgemm_t(dactD[:, G_DCO], actD[:, K_CTX2], seg), _bsum(dactD[:, G_DCO], zs.take(NL, d))
+        gW_1, gb_1 = _bgemm_t(dactF, actD[:, K_N3], seg), _bsum(dactF, zs.take(NL, ff))
+        gW_2, gb_2 = _bgemm_t(dactD[:, G_DF2], actF, seg), _bsum(dactD[:, G_DF2], zs.take(NL, d))
         # gradient of the memory keys / values: contract the per-step score gradients over the steps,
         #   dK_mem[b,h,l,:] = sum_s ds_s[b,h,l] qc_s[b,h,:] ,  dV_mem[b,h,l,:] = sum_s pd_s[b,h,l] dctx2_s[b,h,:]
         # (one batched product per layer and operand), then the K|V projections in one product over all layers
@@ -429,13 +454,13 @@ class _SoftDecode(Function):
                 g_mem = gm
         # LayerNorm gains / biases: sums over all (step, sentence) rows, one launch per LayerNorm kind over all layers
         # (+ the final one)
-        ln_g = e(3 * NL + 1, 2, d, dtype=torch.float32)
+        ln_g = zs.take(3 * NL + 1, 2, d)
         st = stats[:3 * NL].view(NL, 3, 2, -1)
         lg = ln_g[:3 * NL].view(NL, 3, 2, d)
-        _ln_param_grads(dactD[:, G_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0])
-        _ln_param_grads(dactD[:, G_DN2], actD[:, K_H1], st[:, 1, 0], st[:, 1, 1], lg[:, 1])
-        _ln_param_grads(dactD[:, G_DN3], actD[:, K_H2], st[:, 2, 0], st[:, 2, 1], lg[:, 2])
-        _ln_param_grads(g["dnf"], X[NL], stats[3 * NL, 0], stats[3 * NL, 1], ln_g[3 * NL])
+        _ln_param_grads(dactD[:, G_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0], zeroed=True)
+        _ln_param_grads(dactD[:, G_DN2], actD[:, K_H1], st[:, 1, 0], st[:, 1, 1], lg[:, 1], zeroed=True)
+        _ln_param_grads(dactD[:, G_DN3], actD[:, K_H2], st[:, 2, 0], st[:, 2, 1], lg[:, 2], zeroed=True)
+        _ln_param_grads(g["dnf"], X[NL], stats[3 * NL, 0], stats[3 * NL, 1], ln_g[3 * NL], zeroed=True)
         # generator and (soft) embedding table
         dlg = g["dlogits"][:, :V]
         gW_gen = _bgemm_t(dlg, bufs["nf"], seg)

@@ -20,7 +20,7 @@ from torch.autograd.function import once_differentiable
 from . import _lib as L
 from . import decode_engine as DE
 from . import ops
-from .decode_engine import _bgemm_t, _bsum, _colsum, _ln_param_grads, cached_pack
+from .decode_engine import _Zeros, _bgemm_t, _bsum, _colsum, _ln_param_grads, cached_pack
 
 S_N1, S_CTXS, S_H1, S_N2, S_CQ, S_CTXC, S_H2, S_N3 = range(8)
 SG_DN1, SG_DOS, SG_DN2, SG_DCQ, SG_DOC, SG_DN3, SG_DF2 = range(7)
@@ -113,12 +113,14 @@ class _DecoderStack(Function):
         L.check(lib.mssr_decstack_bwd(ctypes.byref(plan), L.stream()), "decstack_bwd")
         actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
         memc, dmem_kv = bufs["memc"], g["dmem_kv"]
-        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, S_N1]), _bsum(dqkv)
-        gW_so, gb_so = _bgemm_t(dactD[:, SG_DOS], actD[:, S_CTXS]), _bsum(dactD[:, SG_DOS])
-        gW_cq, gb_cq = _bgemm_t(dactD[:, SG_DCQ], actD[:, S_N2]), _bsum(dactD[:, SG_DCQ])
-        gW_co, gb_co = _bgemm_t(dactD[:, SG_DOC], actD[:, S_CTXC]), _bsum(dactD[:, SG_DOC])
-        gW_1, gb_1 = _bgemm_t(dactF, actD[:, S_N3]), _bsum(dactF)
-        gW_2, gb_2 = _bgemm_t(dactD[:, SG_DF2], actF), _bsum(dactD[:, SG_DF2])
+        # bias and LayerNorm gradients are float atomics into zeroed memory: ONE fill for all of them
+        zs = _Zeros(NL * (3 * d + 4 * d + ff) + (3 * NL + 1) * 2 * d + 64, dev)
+        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, S_N1]), _bsum(dqkv, zs.take(NL, 3 * d))
+        gW_so, gb_so = _bgemm_t(dactD[:, SG_DOS], actD[:, S_CTXS]), _bsum(dactD[:, SG_DOS], zs.take(NL, d))
+        gW_cq, gb_cq = _bgemm_t(dactD[:, SG_DCQ], actD[:, S_N2]), _bsum(dactD[:, SG_DCQ], zs.take(NL, d))
+        gW_co, gb_co = _bgemm_t(dactD[:, SG_DOC], actD[:, S_CTXC]), _bsum(dactD[:, SG_DOC], zs.take(NL, d))
+        gW_1, gb_1 = _bgemm_t(dactF, actD[:, S_N3]), _bsum(dactF, zs.take(NL, ff))
+        gW_2, gb_2 = _bgemm_t(dactD[:, SG_DF2], actF), _bsum(dactD[:, SG_DF2], zs.take(NL, d))
         # memory-bank projections of all layers: weight gradient [NL*2d, d], bias gradient, input gradient -- one product each
         gW_ckv = ops.gemm(dmem_kv.transpose(0, 1), memc, False, torch.float32).view(NL, 2 * d, d)
         gb_ckv = _colsum(dmem_kv).view(NL, 2 * d)
@@ -127,13 +129,13 @@ class _DecoderStack(Function):
             dmem = ops.gemm(dmem_kv, pk.w_ckv, False, cd).view(B, Ls, d).to(ctx.dtypes[1])
         # LayerNorm gains / biases: one launch per LayerNorm kind over all layers (+ the final one)
         stats = bufs["stats"]
-        ln_g = e(3 * NL + 1, 2, d, dtype=torch.float32)
+        ln_g = zs.take(3 * NL + 1, 2, d)
         st = stats[:3 * NL].view(NL, 3, 2, -1)
         lg = ln_g[:3 * NL].view(NL, 3, 2, d)
-        _ln_param_grads(dactD[:, SG_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0])
-        _ln_param_grads(dactD[:, SG_DN2], actD[:, S_H1], st[:, 1, 0], st[:, 1, 1], lg[:, 1])
-        _ln_param_grads(dactD[:, SG_DN3], actD[:, S_H2], st[:, 2, 0], st[:, 2, 1], lg[:, 2])
-        _ln_param_grads(doutc, X[NL], stats[3 * NL, 0], stats[3 * NL, 1], ln_g[3 * NL])
+        _ln_param_grads(dactD[:, SG_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0], zeroed=True)
+        _ln_param_grads(dactD[:, SG_DN2], actD[:, S_H1], st[:, 1, 0], st[:, 1, 1], lg[:, 1], zeroed=True)
+        _ln_param_grads(dactD[:, SG_DN3], actD[:, S_H2], st[:, 2, 0], st[:, 2, 1], lg[:, 2], zeroed=True)
+        _ln_param_grads(doutc, X[NL], stats[3 * NL, 0], stats[3 * NL, 1], ln_g[3 * NL], zeroed=True)
         dx = g["dX"].view(B, T, d).to(ctx.dtypes[0]) if ctx.needs_input_grad[1] else None
         out = [None, dx, dmem, ln_g[3 * NL, 0], ln_g[3 * NL, 1]]
         for l in range(NL):

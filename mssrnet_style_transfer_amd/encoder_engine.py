@@ -18,7 +18,7 @@ from torch.autograd.function import once_differentiable
 
 from . import _lib as L
 from . import ops
-from .decode_engine import _bgemm_t, _bsum, _ln_param_grads, cached_pack
+from .decode_engine import _Zeros, _bgemm_t, _bsum, _ln_param_grads, cached_pack
 from .weight_pack import JobTable
 
 N_ENC_LAYER_PARAMS = 16
@@ -174,18 +174,20 @@ class _EncoderStack(Function):
             setattr(plan, name, t.data_ptr())
         L.check(lib.mssr_encoder_bwd(ctypes.byref(plan), L.stream()), "encoder_bwd")
         actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
-        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, E_N1]), _bsum(dqkv)
-        gW_o, gb_o = _bgemm_t(dactD[:, EG_DO], actD[:, E_CTX]), _bsum(dactD[:, EG_DO])
-        gW_1, gb_1 = _bgemm_t(dactF, actD[:, E_N2]), _bsum(dactF)
-        gW_2, gb_2 = _bgemm_t(dactD[:, EG_DF2], actF), _bsum(dactD[:, EG_DF2])
+        # bias and LayerNorm gradients are float atomics into zeroed memory: ONE fill for all of them
+        zs = _Zeros(NL * (3 * d + 2 * d + ff) + (2 * NL + 1) * 2 * d + 64, dev)
+        gW_qkv, gb_qkv = _bgemm_t(dqkv, actD[:, E_N1]), _bsum(dqkv, zs.take(NL, 3 * d))
+        gW_o, gb_o = _bgemm_t(dactD[:, EG_DO], actD[:, E_CTX]), _bsum(dactD[:, EG_DO], zs.take(NL, d))
+        gW_1, gb_1 = _bgemm_t(dactF, actD[:, E_N2]), _bsum(dactF, zs.take(NL, ff))
+        gW_2, gb_2 = _bgemm_t(dactD[:, EG_DF2], actF), _bsum(dactD[:, EG_DF2], zs.take(NL, d))
         # LayerNorm gains / biases: one launch per LayerNorm kind over all layers (+ the final one)
         stats = bufs["stats"]
-        ln_g = e(2 * NL + 1, 2, d, dtype=torch.float32)
+        ln_g = zs.take(2 * NL + 1, 2, d)
         st = stats[:2 * NL].view(NL, 2, 2, -1)
         lg = ln_g[:2 * NL].view(NL, 2, 2, d)
-        _ln_param_grads(dactD[:, EG_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0])
-        _ln_param_grads(dactD[:, EG_DN2], actD[:, E_H], st[:, 1, 0], st[:, 1, 1], lg[:, 1])
-        _ln_param_grads(doutc, X[NL], stats[2 * NL, 0], stats[2 * NL, 1], ln_g[2 * NL])
+        _ln_param_grads(dactD[:, EG_DN1], X[:NL], st[:, 0, 0], st[:, 0, 1], lg[:, 0], zeroed=True)
+        _ln_param_grads(dactD[:, EG_DN2], actD[:, E_H], st[:, 1, 0], st[:, 1, 1], lg[:, 1], zeroed=True)
+        _ln_param_grads(doutc, X[NL], stats[2 * NL, 0], stats[2 * NL, 1], ln_g[2 * NL], zeroed=True)
         out = [None, g["dX"].view(B, Ln, d).to(ctx.x_dtype), ln_g[2 * NL, 0], ln_g[2 * NL, 1]]
         for l in range(NL):
             out += [gW_qkv[l, :d], gb_qkv[l, :d], gW_qkv[l, d:2 * d], gb_qkv[l, d:2 * d], gW_qkv[l, 2 * d:],
