@@ -468,6 +468,18 @@ int mssr_decode_step_bwd(const mssr_decode_plan* plan, int step, void* stream);
 /* All steps in one call. */
 int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);
 int mssr_decode_bwd(const mssr_decode_plan* plan, void* stream);
+/* Gradient of the memory keys | values of a decode sweep, all layers in one launch: contracts the per-step slabs the
+ * backward sweep left in plan.ds_ctx [n_layers][2 = ds|pd][T][B*heads][Ls] (float) with the saved context queries
+ * (qc: layer l at qc + l*qc_layer_stride elements, [T][B, d]) and context gradients (dctx, likewise) over the steps:
+ *   out[b, j, l, 0, h, :] = sum_s ds_s[b,h,j] qc_s[b,h,:],  out[b, j, l, 1, h, :] = sum_s pd_s[b,h,j] dctx_s[b,h,:]
+ * with out [B, Ls, n_layers, 2, d] in the compute dtype: the layout of mssr_decode_plan.mem_kv, so its rows feed the
+ * K|V projections' backward directly.  Sentences below b0 are skipped (rows of a mixed sweep without gradient; their
+ * rows of out are not written).  Replaces the autograd backward of the cached context attention's
+ * matmul(attn, value) / matmul(query, key^T) over the step loop (onmt/modules/multi_headed_attn.py:187-205 under
+ * onmt/train_and_translate.py:202-231).  Head width <= 64. */
+int mssr_ctx_kv_grad(const float* ds_ctx, const void* qc, int64_t qc_layer_stride, const void* dctx,
+                     int64_t dctx_layer_stride, void* out, int n_layers, int T, int B, int b0, int heads, int dh, int Ls,
+                     int dtype, void* stream);
 
 /* ------------------------------------------------ teacher-forced decoder-stack engine ------
  * Replaces the Python layer loop of TransformerDecoder.forward with step = None

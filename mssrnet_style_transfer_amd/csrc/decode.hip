@@ -612,6 +612,50 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     }
 }
 
+// Gradient of the memory keys / values of a decode sweep: the backward leaves, per step s, the score gradients ds_s and
+// the dropped probabilities pd_s of every (sentence, head) in the slabs ds_ctx [n_layers][2][T][B*H][Ls] (float); the
+// keys' and values' gradients are their contraction over the steps with the saved queries / context gradients,
+//     dK[b, j, l, h, :] = sum_s ds_s[b,h,j] qc_s[b,h,:] ,   dV[b, j, l, h, :] = sum_s pd_s[b,h,j] dctx2_s[b,h,:] .
+// One wave per (layer, K|V, sentence, head): lane <-> feature, 32 keys of accumulators per pass, the step's 32
+// coefficients fetched by the lanes and broadcast through the scalar lane-read path.  One launch for all layers
+// (before: 2 x n_layers batched products of [Ls, T] x [T, dh] tiles plus a float -> bf16 copy of the slabs).
+template <typename T>
+__global__ __launch_bounds__(256) void ctx_kv_grad_kernel(const float* __restrict__ ds, const T* __restrict__ qc,
+                                                          int64_t qc_ls, const T* __restrict__ dctx, int64_t dctx_ls,
+                                                          T* __restrict__ out, int NL, int Tn, int B, int b0, int H,
+                                                          int dh, int Ls) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t id = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t total = (int64_t)NL * 2 * (B - b0) * H;
+    if (id >= total) return;
+    const int h = (int)(id % H);
+    const int b = b0 + (int)((id / H) % (B - b0));
+    const int which = (int)((id / ((int64_t)H * (B - b0))) % 2);
+    const int l = (int)(id / ((int64_t)H * (B - b0) * 2));
+    const int d = H * dh;
+    const T* rhs = (which ? dctx + (int64_t)l * dctx_ls : qc + (int64_t)l * qc_ls) + (int64_t)b * d + h * dh +
+                   (lane < dh ? lane : dh - 1);
+    const float* cf = ds + ((((int64_t)l * 2 + which) * Tn) * B * H + (int64_t)b * H + h) * Ls;
+    T* o = out + ((((int64_t)b * Ls) * NL + l) * 2 + which) * d + h * dh + lane;
+    for (int j0 = 0; j0 < Ls; j0 += 32) {
+        float acc[32];
+#pragma unroll
+        for (int j = 0; j < 32; ++j) acc[j] = 0.f;
+        const int jl = j0 + (lane & 31) < Ls ? j0 + (lane & 31) : Ls - 1;
+        for (int t = 0; t < Tn; ++t) {
+            const float c = cf[(int64_t)t * B * H * Ls + jl];
+            const float r = to_f(rhs[(int64_t)t * B * d]);
+#pragma unroll
+            for (int j = 0; j < 32; ++j) acc[j] += lane_read(c, j) * r;
+        }
+        if (lane < dh) {
+#pragma unroll
+            for (int j = 0; j < 32; ++j)
+                if (j0 + j < Ls) o[(int64_t)(j0 + j) * NL * 2 * d] = from_f<T>(acc[j]);
+        }
+    }
+}
+
 // x0 = dropout(e * s + pe[step])   (Embeddings soft path epilogue, onmt/modules/embeddings.py:48-53)
 template <typename T>
 __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict__ e, const float* __restrict__ pe,
@@ -1375,4 +1419,25 @@ extern "C" int mssr_decode_fwd(const mssr_decode_plan* p, void* stream) {
 extern "C" int mssr_decode_bwd(const mssr_decode_plan* p, void* stream) {
     MSSR_REQUIRE(p, "decode_bwd: null plan");
     return run_steps(p, 0, p->T, true, (hipStream_t)stream, "decode_bwd");
+}
+
+extern "C" int mssr_ctx_kv_grad(const float* ds_ctx, const void* qc, int64_t qc_layer_stride, const void* dctx,
+                                int64_t dctx_layer_stride, void* out, int n_layers, int T, int B, int b0, int heads,
+                                int dh, int Ls, int dtype, void* stream) {
+    MSSR_REQUIRE(ds_ctx && qc && dctx && out, "ctx_kv_grad: null pointer");
+    MSSR_REQUIRE(valid_dtype(dtype), "ctx_kv_grad: bad dtype");
+    MSSR_REQUIRE(n_layers > 0 && T > 0 && B > 0 && b0 >= 0 && b0 < B && heads > 0 && dh > 0 && dh <= 64 && Ls > 0,
+                 "ctx_kv_grad: bad dimensions (head width must be <= 64)");
+    const int64_t waves = (int64_t)n_layers * 2 * (B - b0) * heads;
+    MSSR_REQUIRE((waves + 3) / 4 < ((int64_t)1 << 31), "ctx_kv_grad: too many slices");
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    if (dtype == MSSR_F32)
+        ctx_kv_grad_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>(ds_ctx, (const float*)qc, qc_layer_stride,
+                                                                         (const float*)dctx, dctx_layer_stride,
+                                                                         (float*)out, n_layers, T, B, b0, heads, dh, Ls);
+    else
+        ctx_kv_grad_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>(ds_ctx, (const bf16*)qc, qc_layer_stride,
+                                                                        (const bf16*)dctx, dctx_layer_stride, (bf16*)out,
+                                                                        n_layers, T, B, b0, heads, dh, Ls);
+    MSSR_LAUNCH_OK("ctx_kv_grad");
 }

@@ -435,11 +435,17 @@ class _SoftDecode(Function):
         # (one batched product per layer and operand), then the K|V projections in one product over all layers
         dh = d // H
         dmem_kv = e(B, Ls, NL, 2, H, dh)
-        dsc = g["ds_ctx"].to(cd).view(NL, 2, T, B, H, Ls)
-        for l in range(NL):
-            for which, rhs in ((0, actD[l, K_QC]), (1, g["dctx"][l, 1])):
-                ops.gemm(dsc[l, which].permute(1, 2, 3, 0), rhs.view(T, B, H, dh).permute(1, 2, 0, 3), False, cd,
-                         out=dmem_kv[:, :, l, which].permute(0, 2, 1, 3))
+        if dh <= 64:        # one launch for all layers, keys and values (csrc/decode.hip: ctx_kv_grad_kernel)
+            qc_all, dctx2_all = actD[:, K_QC], g["dctx"][:, 1]
+            L.check(lib.mssr_ctx_kv_grad(g["ds_ctx"].data_ptr(), qc_all.data_ptr(), qc_all.stride(0), dctx2_all.data_ptr(),
+                                         dctx2_all.stride(0), dmem_kv.data_ptr(), NL, T, B, E0, H, dh, Ls, plan.dtype,
+                                         L.stream()), "ctx_kv_grad")
+        else:
+            dsc = g["ds_ctx"].to(cd).view(NL, 2, T, B, H, Ls)
+            for l in range(NL):
+                for which, rhs in ((0, actD[l, K_QC]), (1, g["dctx"][l, 1])):
+                    ops.gemm(dsc[l, which].permute(1, 2, 3, 0), rhs.view(T, B, H, dh).permute(1, 2, 0, 3), False, cd,
+                             out=dmem_kv[:, :, l, which].permute(0, 2, 1, 3))
         dmem_kv = dmem_kv.view(B * Ls, NL * 2 * d)[E0 * Ls:]            # rows of the sentences that carry gradient
         gW_ckv = _bgemm_t(dmem_kv, bufs["mem"][E0 * Ls:]).view(NL, 2 * d, d)
         gb_ckv = _colsum(dmem_kv).view(NL, 2 * d)

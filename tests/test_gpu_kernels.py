@@ -889,3 +889,26 @@ def test_gemm_wide_vocabulary_kernel(ops, M, N, K, ln):
         rec += ops.stop_profile()
         assert_close(out2.float(), (x.double() @ wb.double().t() + b.double()).float(), 1e-2, "wide, bias, bf16 out")
     assert any(r["kernel"].startswith("gemm_wide_kernel") for r in rec), [r["kernel"] for r in rec]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("NL,T,B,b0,H,dh,Ls", [(3, 7, 5, 0, 8, 64, 18), (2, 28, 6, 2, 4, 32, 40), (1, 3, 9, 8, 2, 16, 1)])
+def test_ctx_kv_grad_kernel(ops, dtype, NL, T, B, b0, H, dh, Ls):
+    """Memory key / value gradients of a decode sweep (mssr_ctx_kv_grad): the per-step score-gradient slabs contracted
+    with the saved queries / context gradients over the steps, all layers in one launch, against a float64 einsum;
+    sentences below b0 (the eval rows of a mixed sweep) are left untouched."""
+    from mssrnet_style_transfer_amd import _lib as L
+    torch.manual_seed(NL * 100 + T + B)
+    d = H * dh
+    ds = torch.randn(NL, 2, T, B * H, Ls, device="cuda")
+    act = torch.randn(NL, 8, T * B, d, device="cuda").to(dtype)          # queries live in a strided slab, kind 4
+    dctx = torch.randn(NL, 2, T * B, d, device="cuda").to(dtype)
+    qc, dc = act[:, 4], dctx[:, 1]
+    out = torch.full((B, Ls, NL, 2, H, dh), 7.0, device="cuda", dtype=dtype)
+    L.check(L.load().mssr_ctx_kv_grad(ds.data_ptr(), qc.data_ptr(), qc.stride(0), dc.data_ptr(), dc.stride(0), out.data_ptr(),
+                                      NL, T, B, b0, H, dh, Ls, L.dt(out), L.stream()), "ctx_kv_grad")
+    dsv = ds.view(NL, 2, T, B, H, Ls).double()
+    want = torch.stack([torch.einsum("ltbhj,ltbhe->bjlhe", dsv[:, 0], qc.reshape(NL, T, B, H, dh).double()),
+                        torch.einsum("ltbhj,ltbhe->bjlhe", dsv[:, 1], dc.reshape(NL, T, B, H, dh).double())], 3)
+    assert_close(out[b0:], want[b0:].float(), 1e-5 if dtype == torch.float32 else 8e-3, "ctx_kv_grad")
+    assert bool((out[:b0] == 7.0).all())
