@@ -22,7 +22,10 @@
 // has finished reading buf[t&1] before the DMA of tile t+2 overwrites it (WAR).  64 KB of LDS -> 2 blocks per CU,
 // whose K-steps overlap each other's barrier waits.  Measured alternatives (32768 x 512 x 512, bf16): this form
 // 34.4 us; a ring of four BK = 32 buffers with three K-steps in flight behind counted vmcnt + raw s_barrier 38.4 us
-// (twice the barriers per MFMA); the register-staged BK = 32 kernel of gemm.hip 96.6 us.  A 128 x 128 tile needs
+// (twice the barriers per MFMA); the register-staged BK = 32 kernel of gemm.hip 96.6 us.  For grids of <= 256 blocks (one
+// block per CU, nothing to overlap a K-step's DMA with) a ring of four BK = 64 stages, two K-steps in flight behind
+// counted vmcnt and one raw barrier per step, was SLOWER: 2560 x 1024 x 512 13.5 -> 15.5 us, 2560 x 512 x 1024 18.0 ->
+// 22.2 us (scratch/pipe_bench.py) -- those launches are not waiting for their DMA.  A 128 x 128 tile needs
 // 64 B of operand per 4096 flop, i.e. the CU's whole 64 B/clk vector-memory path at the MFMA peak: ~600 TFLOP/s is
 // what this tile shape reaches (measured 616 on a 9632 x 512 x 71680 weight gradient); beyond that needs 256-wide tiles.
 //
