@@ -192,6 +192,19 @@ int mssr_mask_scale(const void* x, const uint8_t* mask, const void* residual, vo
                     float scale, int dtype, void* stream);
 /* y = x * (gate > 0): ReLU backward as an op (position_ffn.py:35). */
 int mssr_gate_gt0(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream);
+/* WGAN-GP penalty of per-token input gradients (penalize_gen_style_grad / penalize_gen_text_grad,
+ * onmt/trainer_wgan_wh.py:1253-1261, :1321-1329: gradients.norm(2, dim=1) over the rows the sequence mask selects,
+ * ((norm - k) ** 2).mean() * lamb) in one launch.  Row (i0, i1), i0 < n0, i1 < n1, is g + i0*s0 + i1*s1 (elements, d
+ * contiguous values) and mask + i0*m0 + i1*m1 (uint8, != 0: selected).  norms [n0*n1] receives every row's norm;
+ * acc: float[4] ZEROED by the caller, on return acc[0] = sum of (norm - k)^2, acc[1] = selected rows, acc[3] = the
+ * penalty (acc[2] is the kernel's ticket).  No selected row -> NaN, as the reference's mean of an empty tensor. */
+int mssr_gp_penalty_fwd(const void* g, int64_t s0, int64_t s1, int n0, int n1, int d, const uint8_t* mask, int64_t m0,
+                        int64_t m1, float k, float lamb, float* norms, float* acc, int dtype, void* stream);
+/* Its gradient: dg [n0*n1, d] contiguous = dpen[0] * lamb / acc[1] * 2 (norm - k) / norm * g on selected rows (0 at
+ * norm = 0: the subgradient torch's norm backward uses), 0 elsewhere; norms / acc as left by the forward. */
+int mssr_gp_penalty_bwd(const void* g, int64_t s0, int64_t s1, int n0, int n1, int d, const uint8_t* mask, int64_t m0,
+                        int64_t m1, float k, float lamb, const float* norms, const float* acc, const float* dpen,
+                        void* dg, int dtype, void* stream);
 /* out[n] (+)= sum over rows of x[rows, n] (Linear bias gradient). */
 int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int accumulate,
                 int dtype, void* stream);

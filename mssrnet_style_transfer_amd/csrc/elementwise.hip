@@ -245,6 +245,91 @@ __global__ __launch_bounds__(EW_BLOCK) void scale_add_pe_kernel(const T* __restr
     }
 }
 
+// ------------------------------------------------------------------ WGAN-GP penalty of per-token gradients
+//   penalty = lamb * mean over the rows with mask != 0 of (||g_row||_2 - k)^2
+// (onmt/trainer_wgan_wh.py:1253-1261, :1321-1329: gradients.norm(2, dim=1), ((norm - k) ** 2).mean() * lamb on the
+// rows selected by the sequence mask).  Rows are addressed (i0, i1) -> g + i0*s0 + i1*s1, so the [T, B, V] slice the
+// autograd graph hands over is read where it lies; the penalty is a sum over rows, their order does not matter.
+// A block per row (grid-stride beyond 512 rows); the last block to finish (ticket) divides by the count and writes the
+// scalar.
+// acc: float[4] zeroed by the caller = {sum of (norm-k)^2, selected rows, ticket, result}.
+template <typename T>
+__global__ __launch_bounds__(256) void gp_penalty_fwd_kernel(const T* __restrict__ g, int64_t s0, int64_t s1, int n0,
+                                                             int n1, int d, const uint8_t* __restrict__ mask,
+                                                             int64_t m0, int64_t m1, float k, float lamb,
+                                                             float* __restrict__ norms, float* __restrict__ acc) {
+    __shared__ float part[4];
+    float pen = 0.f, cnt = 0.f;                      // this block's rows (thread 0)
+    for (int row = blockIdx.x; row < n0 * n1; row += gridDim.x) {
+        const int i0 = row / n1, i1 = row - i0 * n1;
+        const T* gr = g + (int64_t)i0 * s0 + (int64_t)i1 * s1;
+        float ss = 0.f;
+        for (int c0 = threadIdx.x; c0 < d; c0 += 256 * 8) {        // 8 independent loads in flight per thread
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + u * 256;
+                v[u] = to_f(gr[c < d ? c : d - 1]);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (c0 + u * 256 < d) ss += v[u] * v[u];
+        }
+        ss = wave_sum(ss);
+        __syncthreads();                             // part[] of the previous row has been read
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = ss;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float norm = sqrtf((part[0] + part[1]) + (part[2] + part[3]));
+            norms[row] = norm;
+            if (mask[(int64_t)i0 * m0 + (int64_t)i1 * m1]) {
+                pen += (norm - k) * (norm - k);
+                cnt += 1.0f;
+            }
+        }
+    }
+    if (threadIdx.x == 0) {
+        // a few hundred blocks, three atomics each (one block per row: ~1 400 x 3 same-line atomics took 85 us)
+        atomicAdd(acc, pen);
+        atomicAdd(acc + 1, cnt);
+        __threadfence();
+        const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(acc + 2), 1u);
+        if (done == gridDim.x - 1) {
+            __threadfence();
+            const float sum = atomicAdd(acc, 0.f), n = atomicAdd(acc + 1, 0.f);       // device-scope reads
+            acc[3] = sum / n * lamb;
+        }
+    }
+}
+
+// dg_row = dpen * lamb / count * 2 (norm - k) / norm * g_row on selected rows (0 where norm = 0, as vector_norm's
+// backward), 0 elsewhere; dg is contiguous [rows, d]
+template <typename T>
+__global__ __launch_bounds__(256) void gp_penalty_bwd_kernel(const T* __restrict__ g, int64_t s0, int64_t s1, int n1,
+                                                             int d, const uint8_t* __restrict__ mask, int64_t m0,
+                                                             int64_t m1, float k, float lamb,
+                                                             const float* __restrict__ norms,
+                                                             const float* __restrict__ acc,
+                                                             const float* __restrict__ dpen, T* __restrict__ dg) {
+    const int row = blockIdx.x, i0 = row / n1, i1 = row - i0 * n1;
+    const T* gr = g + (int64_t)i0 * s0 + (int64_t)i1 * s1;
+    T* out = dg + (int64_t)row * d;
+    const float norm = norms[row];
+    float coef = 0.f;
+    if (mask[(int64_t)i0 * m0 + (int64_t)i1 * m1] && norm > 0.f) coef = dpen[0] * lamb / acc[1] * 2.0f * (norm - k) / norm;
+    for (int c0 = threadIdx.x; c0 < d; c0 += 256 * 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u * 256;
+            v[u] = to_f(gr[c < d ? c : d - 1]);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (c0 + u * 256 < d) out[c0 + u * 256] = from_f<T>(coef * v[u]);
+    }
+}
+
 }  // namespace mssr
 
 using namespace mssr;
@@ -415,4 +500,37 @@ extern "C" int mssr_scale_add_pe(const void* x, const float* pe, void* out, int6
     else
         scale_add_pe_kernel<bf16><<<dim3(g), dim3(EW_BLOCK), 0, s>>>((const bf16*)x, pe, (bf16*)out, rows, d, batch, step, scale);
     MSSR_LAUNCH_OK("scale_add_pe");
+}
+
+extern "C" int mssr_gp_penalty_fwd(const void* g, int64_t s0, int64_t s1, int n0, int n1, int d, const uint8_t* mask,
+                                   int64_t m0, int64_t m1, float k, float lamb, float* norms, float* acc, int dtype,
+                                   void* stream) {
+    MSSR_REQUIRE(g && mask && norms && acc, "gp_penalty_fwd: null pointer");
+    MSSR_REQUIRE(valid_dtype(dtype), "gp_penalty_fwd: bad dtype");
+    MSSR_REQUIRE(n0 > 0 && n1 > 0 && d > 0 && (int64_t)n0 * n1 < ((int64_t)1 << 31), "gp_penalty_fwd: bad dimensions");
+    const int rows = n0 * n1;
+    const dim3 grid((unsigned)(rows < 512 ? rows : 512));
+    if (dtype == MSSR_F32)
+        gp_penalty_fwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)g, s0, s1, n0, n1, d, mask, m0,
+                                                                            m1, k, lamb, norms, acc);
+    else
+        gp_penalty_fwd_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16*)g, s0, s1, n0, n1, d, mask, m0, m1,
+                                                                           k, lamb, norms, acc);
+    MSSR_LAUNCH_OK("gp_penalty_fwd");
+}
+
+extern "C" int mssr_gp_penalty_bwd(const void* g, int64_t s0, int64_t s1, int n0, int n1, int d, const uint8_t* mask,
+                                   int64_t m0, int64_t m1, float k, float lamb, const float* norms, const float* acc,
+                                   const float* dpen, void* dg, int dtype, void* stream) {
+    MSSR_REQUIRE(g && mask && norms && acc && dpen && dg, "gp_penalty_bwd: null pointer");
+    MSSR_REQUIRE(valid_dtype(dtype), "gp_penalty_bwd: bad dtype");
+    MSSR_REQUIRE(n0 > 0 && n1 > 0 && d > 0 && (int64_t)n0 * n1 < ((int64_t)1 << 31), "gp_penalty_bwd: bad dimensions");
+    const dim3 grid((unsigned)(n0 * n1));
+    if (dtype == MSSR_F32)
+        gp_penalty_bwd_kernel<float><<<grid, 256, 0, (hipStream_t)stream>>>((const float*)g, s0, s1, n1, d, mask, m0, m1, k,
+                                                                            lamb, norms, acc, dpen, (float*)dg);
+    else
+        gp_penalty_bwd_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16*)g, s0, s1, n1, d, mask, m0, m1, k,
+                                                                           lamb, norms, acc, dpen, (bf16*)dg);
+    MSSR_LAUNCH_OK("gp_penalty_bwd");
 }

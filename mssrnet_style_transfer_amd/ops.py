@@ -800,6 +800,49 @@ class second_order:
         _tls.second_order = self.prev
 
 
+class _GpPenalty(Function):
+    """lamb * mean over the masked rows of (||g_row|| - k)^2 in one launch (csrc/elementwise.hip, mssr_gp_penalty_*).
+    g [n0, n1, d] with any row strides (d contiguous), mask Bool [n0, n1] with any strides.  g carries the graph of
+    the critic's input gradient; this node's own backward is first order (the penalty is differentiated once)."""
+
+    @staticmethod
+    def forward(ctx, g, mask, k, lamb):
+        n0, n1, d = g.shape
+        m8 = mask.view(torch.uint8)
+        norms = torch.empty(n0 * n1, dtype=torch.float32, device=g.device)
+        acc = torch.zeros(4, dtype=torch.float32, device=g.device)
+        L.check(L.load().mssr_gp_penalty_fwd(g.data_ptr(), g.stride(0), g.stride(1), n0, n1, d, m8.data_ptr(), m8.stride(0),
+                                             m8.stride(1), k, lamb, norms.data_ptr(), acc.data_ptr(), L.dt(g), L.stream()),
+                "gp_penalty_fwd")
+        ctx.save_for_backward(g, m8, norms, acc)
+        ctx.k, ctx.lamb = k, lamb
+        return acc[3]
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dpen):
+        g, m8, norms, acc = ctx.saved_tensors
+        n0, n1, d = g.shape
+        dg = torch.empty(n0, n1, d, dtype=g.dtype, device=g.device)
+        dp = dpen.to(torch.float32).reshape(1).contiguous()
+        L.check(L.load().mssr_gp_penalty_bwd(g.data_ptr(), g.stride(0), g.stride(1), n0, n1, d, m8.data_ptr(), m8.stride(0),
+                                             m8.stride(1), ctx.k, ctx.lamb, norms.data_ptr(), acc.data_ptr(), dp.data_ptr(),
+                                             dg.data_ptr(), L.dt(g), L.stream()), "gp_penalty_bwd")
+        return dg, None, None, None
+
+
+def gp_penalty(g, mask, k, lamb):
+    """WGAN-GP penalty of per-token gradients g [n0, n1, d] over the rows where mask [n0, n1] (Bool) is set:
+    ((||g_row||_2 - k) ** 2).mean() * lamb (onmt/trainer_wgan_wh.py:1253-1261, :1321-1329), float32 scalar."""
+    L.require_cuda(g, mask)
+    if g.dim() != 3 or mask.shape != g.shape[:2] or mask.dtype != torch.bool:
+        raise ValueError("gp_penalty: g [n0, n1, d] and a Bool mask [n0, n1] expected (got %s, %s %s)" % (
+            tuple(g.shape), tuple(mask.shape), mask.dtype))
+    if g.stride(2) != 1 and g.shape[2] > 1:
+        g = g.contiguous()
+    return _GpPenalty.apply(g, mask, float(k), float(lamb))
+
+
 def second_order_active():
     return getattr(_tls, "second_order", False)
 

@@ -37,14 +37,12 @@ def _to_device_async(t, like):
     return t.to(like.dtype).pin_memory().to(like.device, non_blocking=True)
 
 
-def _masked_penalty(g2d, mask, k, lamb):
-    """((||g_i|| - k)^2 over the rows where mask is set).mean() * lamb, as g2d[mask] would give it but without
-    boolean indexing (nonzero = a device sync in the middle of the phase)."""
-    # vector_norm's backward is 0 at a zero row (as the reference's gradients.norm(2, dim=1)); sqrt(sum g^2) would
-    # turn a valid all-zero gradient row into inf * 0 = NaN in the critic's gradients
-    norm = torch.linalg.vector_norm(g2d.float(), dim=1)
-    pen = torch.where(mask, (norm - k) ** 2, torch.zeros_like(norm))
-    return pen.sum() / mask.sum() * lamb
+def _masked_penalty(g, mask, k, lamb):
+    """((||g_i|| - k)^2 over the rows where mask is set).mean() * lamb for g [n0, n1, dim] and mask Bool [n0, n1], as
+    g[mask] would give it but without boolean indexing (nonzero = a device sync in the middle of the phase) and in
+    one launch, reading g in whatever row order the graph left it (ops.gp_penalty; the gradient of a zero row is 0,
+    as with the reference's gradients.norm(2, dim=1))."""
+    return ops.gp_penalty(g, mask, k, lamb)
 
 
 def convert_sent_ids_to_onehot(sent_ids, vocab_size):
@@ -62,8 +60,7 @@ def penalize_gen_style_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10
         err = cal_disc_loss(d_model(inter, lengths), labels)
     g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     if gp_norm_seq:
-        return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
-                               sequence_mask(lengths, max_len=real.size(1)).contiguous().view(-1), k, lamb)
+        return _masked_penalty(g, sequence_mask(lengths, max_len=real.size(1)), k, lamb)
     return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
 
 
@@ -77,8 +74,7 @@ def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.
     g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     g = g.transpose(0, 1)
     if gp_norm_seq:
-        return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
-                               sequence_mask(lengths, max_len=x_len).contiguous().view(-1), k, lamb)
+        return _masked_penalty(g, sequence_mask(lengths, max_len=x_len), k, lamb)
     return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
 
 
@@ -317,8 +313,7 @@ class Trainer:
     def _penalty(self, g, lengths, max_len, k, lamb):
         """gradient penalty of per-token input gradients g [B, L, dim] (penalize_gen_*_grad, :1253-1261, :1321-1329)."""
         if self.cfg.use_gp_norm_seq:
-            return _masked_penalty(g.contiguous().view(-1, g.size(-1)),
-                                   sequence_mask(lengths, max_len=max_len).contiguous().view(-1), k, lamb)
+            return _masked_penalty(g, sequence_mask(lengths, max_len=max_len), k, lamb)
         return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
 
     def _text_critic_batched(self, vocab_target, probs, text_len, labels, alpha_t):

@@ -912,3 +912,34 @@ def test_ctx_kv_grad_kernel(ops, dtype, NL, T, B, b0, H, dh, Ls):
                         torch.einsum("ltbhj,ltbhe->bjlhe", dsv[:, 1], dc.reshape(NL, T, B, H, dh).double())], 3)
     assert_close(out[b0:], want[b0:].float(), 1e-5 if dtype == torch.float32 else 8e-3, "ctx_kv_grad")
     assert bool((out[:b0] == 7.0).all())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("n0,n1,d,strided", [(18, 80, 9606, True), (80, 16, 256, False), (3, 2, 7, True)])
+def test_gp_penalty_kernel(ops, dtype, n0, n1, d, strided):
+    """WGAN-GP penalty of per-token gradients in one launch (ops.gp_penalty) against the reference's formula
+    ((g[mask].norm(2, dim=1) - k) ** 2).mean() * lamb (trainer_wgan_wh.py:1253-1261) in float64, value and gradient,
+    on a strided slice of a larger gradient (what torch.cat's backward hands over) and a transposed mask; a selected
+    row whose gradient is exactly zero contributes (0 - k)^2 with a zero subgradient, not inf * 0 = NaN."""
+    torch.manual_seed(n0 * n1 + d)
+    full = torch.randn(n0, 2 * n1 if strided else n1, d, device="cuda").to(dtype)
+    full[1, -1] = 0                                            # a zero gradient row inside the mask
+    full.requires_grad_(True)
+    g = full[:, n1:] if strided else full
+    mask = (torch.rand(n1, n0, device="cuda") < 0.7).t()       # [n0, n1], transposed strides
+    mask[1, -1] = True
+    mask[0, 0] = False
+    k, lamb = 1.0, 10.0
+    pen = ops.gp_penalty(g, mask, k, lamb)
+    pen.backward(torch.tensor(0.5, device="cuda"))
+    ref_in = full.detach().double().requires_grad_(True)
+    gr = ref_in[:, n1:] if strided else ref_in
+    want = ((gr[mask].norm(2, dim=1) - k) ** 2).mean() * lamb
+    want.backward(torch.tensor(0.5, device="cuda", dtype=torch.float64))
+    assert abs(float(pen) - float(want)) <= 1e-4 * abs(float(want))
+    assert pen.dtype == torch.float32
+    assert_close(full.grad.float(), ref_in.grad.float(), 1e-5 if dtype == torch.float32 else 8e-3, "gp_penalty gradient")
+    assert bool(torch.isfinite(full.grad).all())
+    assert float(full.grad[1, -1].abs().max()) == 0.0 and float(full.grad[:, n1:][0, 0].abs().max() if strided else full.grad[0, 0].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.gp_penalty(g.detach().cpu(), mask.cpu(), k, lamb)   # no CPU path
