@@ -192,6 +192,19 @@ int mssr_mask_scale(const void* x, const uint8_t* mask, const void* residual, vo
                     float scale, int dtype, void* stream);
 /* y = x * (gate > 0): ReLU backward as an op (position_ffn.py:35). */
 int mssr_gate_gt0(const void* x, const void* gate, void* y, int64_t n, int dtype, void* stream);
+/* Critic gain at the label column: out[i] = ratio * sigmoid(x[i, labels[i]]) (sigmoid != 0: the "sigmoid"
+ * force_positive_gain_mode, onmt/trainer_wgan_wh.py:402-416) or x[i, labels[i]] ("normal"), i.e. the gain followed by
+ * cal_disc_loss's per-row pick (:1192-1200) in one launch; x float [n, C] with row stride ldx, labels int64 [n].
+ * _bwd: dx [n, C] contiguous = onehot(labels) * dy * f'(x).  _bwd_bwd: the derivative of _bwd w.r.t. (dy, x) for an
+ * incoming ddx [n, C] (row stride ldd): ddy [n], dx2 [n, C] -- the gradient penalty differentiates the critic's input
+ * gradient, which runs through _bwd.  A label outside [0, C) gives NaN. */
+int mssr_gain_pick_fwd(const float* x, int64_t ldx, const int64_t* labels, float* out, int n, int C, float ratio,
+                       int sigmoid, void* stream);
+int mssr_gain_pick_bwd(const float* dy, const float* x, int64_t ldx, const int64_t* labels, float* dx, int n, int C,
+                       float ratio, int sigmoid, void* stream);
+int mssr_gain_pick_bwd_bwd(const float* ddx, int64_t ldd, const float* dy, const float* x, int64_t ldx,
+                           const int64_t* labels, float* ddy, float* dx2, int n, int C, float ratio, int sigmoid,
+                           void* stream);
 /* WGAN-GP penalty of per-token input gradients (penalize_gen_style_grad / penalize_gen_text_grad,
  * onmt/trainer_wgan_wh.py:1253-1261, :1321-1329: gradients.norm(2, dim=1) over the rows the sequence mask selects,
  * ((norm - k) ** 2).mean() * lamb) in one launch.  Row (i0, i1), i0 < n0, i1 < n1, is g + i0*s0 + i1*s1 (elements, d

@@ -127,6 +127,9 @@ SIGNATURES = {
     "mssr_dropout_fwd": ([_P, _P, _P, _P, _L, _F, _U, _I, _P], c_int),
     "mssr_mask_scale": ([_P, _P, _P, _P, _L, _F, _I, _P], c_int),
     "mssr_gate_gt0": ([_P, _P, _P, _L, _I, _P], c_int),
+    "mssr_gain_pick_fwd": ([_P, _L, _P, _P, _I, _I, _F, _I, _P], c_int),
+    "mssr_gain_pick_bwd": ([_P, _P, _L, _P, _P, _I, _I, _F, _I, _P], c_int),
+    "mssr_gain_pick_bwd_bwd": ([_P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _F, _I, _P], c_int),
     "mssr_gp_penalty_fwd": ([_P, _L, _L, _I, _I, _I, _P, _L, _L, _F, _F, _P, _P, _I, _P], c_int),
     "mssr_gp_penalty_bwd": ([_P, _L, _L, _I, _I, _I, _P, _L, _L, _F, _F, _P, _P, _P, _P, _I, _P], c_int),
     "mssr_colsum": ([_P, _P, _L, _I, _L, _I, _I, _P], c_int),

@@ -330,6 +330,78 @@ __global__ __launch_bounds__(256) void gp_penalty_bwd_kernel(const T* __restrict
     }
 }
 
+// ------------------------------------------------------------------ critic gain at the label column
+//   picked_i = ratio * sigmoid(x[i, l_i])   (force_positive_gain_mode "sigmoid": onmt/trainer_wgan_wh.py:402-416)
+//   picked_i = x[i, l_i]                    ("normal")
+// followed by cal_disc_loss's per-row pick (:1192-1200), as one op with its first and second derivative: the
+// gradient penalty differentiates the critic's input gradient, which passes through this op's backward.
+// A label outside [0, C) yields NaN (the reference's indexing would raise).
+__device__ __forceinline__ float gp_sig(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void gain_pick_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                            const int64_t* __restrict__ labels, float* __restrict__ out,
+                                                            int n, int C, float ratio, int sig) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t l = labels[i];
+    if (l < 0 || l >= C) { out[i] = NAN; return; }
+    const float v = x[(int64_t)i * ldx + l];
+    out[i] = sig ? ratio * gp_sig(v) : v;
+}
+
+// dx[i, c] = (c == l_i) dy_i f'(x[i, l_i])            (dx contiguous [n, C])
+__global__ __launch_bounds__(256) void gain_pick_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            int64_t ldx, const int64_t* __restrict__ labels,
+                                                            float* __restrict__ dx, int n, int C, float ratio, int sig) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * C) return;
+    const int i = e / C, c = e - i * C;
+    const int64_t l = labels[i];
+    float o = 0.f;
+    if (l < 0 || l >= C) o = NAN;
+    else if (c == l) {
+        float d1 = 1.0f;
+        if (sig) {
+            const float sg = gp_sig(x[(int64_t)i * ldx + l]);
+            d1 = ratio * sg * (1.0f - sg);
+        }
+        o = dy[i] * d1;
+    }
+    dx[e] = o;
+}
+
+// backward of the above w.r.t. (dy, x) given ddx [n, C] (row stride ldd):
+//   ddy_i = ddx[i, l_i] f'(x_il) ,   dx2[i, c] = (c == l_i) ddx[i, l_i] dy_i f''(x_il)
+__global__ __launch_bounds__(256) void gain_pick_bwd_bwd_kernel(const float* __restrict__ ddx, int64_t ldd,
+                                                                const float* __restrict__ dy,
+                                                                const float* __restrict__ x, int64_t ldx,
+                                                                const int64_t* __restrict__ labels,
+                                                                float* __restrict__ ddy, float* __restrict__ dx2, int n,
+                                                                int C, float ratio, int sig) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n * C) return;
+    const int i = e / C, c = e - i * C;
+    const int64_t l = labels[i];
+    if (l < 0 || l >= C) {
+        dx2[e] = NAN;
+        if (c == 0) ddy[i] = NAN;
+        return;
+    }
+    float o = 0.f;
+    if (c == l) {
+        const float g = ddx[(int64_t)i * ldd + l];
+        float d1 = 1.0f, d2 = 0.f;
+        if (sig) {
+            const float sg = gp_sig(x[(int64_t)i * ldx + l]);
+            d1 = ratio * sg * (1.0f - sg);
+            d2 = d1 * (1.0f - 2.0f * sg);
+        }
+        ddy[i] = g * d1;
+        o = g * dy[i] * d2;
+    }
+    dx2[e] = o;
+}
+
 }  // namespace mssr
 
 using namespace mssr;
@@ -533,4 +605,32 @@ extern "C" int mssr_gp_penalty_bwd(const void* g, int64_t s0, int64_t s1, int n0
         gp_penalty_bwd_kernel<bf16><<<grid, 256, 0, (hipStream_t)stream>>>((const bf16*)g, s0, s1, n1, d, mask, m0, m1, k,
                                                                            lamb, norms, acc, dpen, (bf16*)dg);
     MSSR_LAUNCH_OK("gp_penalty_bwd");
+}
+
+extern "C" int mssr_gain_pick_fwd(const float* x, int64_t ldx, const int64_t* labels, float* out, int n, int C,
+                                  float ratio, int sigmoid, void* stream) {
+    MSSR_REQUIRE(x && labels && out && n > 0 && C > 0 && ldx >= C, "gain_pick_fwd: bad arguments");
+    gain_pick_fwd_kernel<<<dim3((unsigned)((n + 255) / 256)), 256, 0, (hipStream_t)stream>>>(x, ldx, labels, out, n, C,
+                                                                                           ratio, sigmoid);
+    MSSR_LAUNCH_OK("gain_pick_fwd");
+}
+
+extern "C" int mssr_gain_pick_bwd(const float* dy, const float* x, int64_t ldx, const int64_t* labels, float* dx, int n,
+                                  int C, float ratio, int sigmoid, void* stream) {
+    MSSR_REQUIRE(dy && x && labels && dx && n > 0 && C > 0 && ldx >= C && (int64_t)n * C < ((int64_t)1 << 31),
+                 "gain_pick_bwd: bad arguments");
+    gain_pick_bwd_kernel<<<dim3((unsigned)((n * C + 255) / 256)), 256, 0, (hipStream_t)stream>>>(dy, x, ldx, labels, dx, n,
+                                                                                               C, ratio, sigmoid);
+    MSSR_LAUNCH_OK("gain_pick_bwd");
+}
+
+extern "C" int mssr_gain_pick_bwd_bwd(const float* ddx, int64_t ldd, const float* dy, const float* x, int64_t ldx,
+                                      const int64_t* labels, float* ddy, float* dx2, int n, int C, float ratio,
+                                      int sigmoid, void* stream) {
+    MSSR_REQUIRE(ddx && dy && x && labels && ddy && dx2 && n > 0 && C > 0 && ldx >= C && ldd >= C &&
+                     (int64_t)n * C < ((int64_t)1 << 31),
+                 "gain_pick_bwd_bwd: bad arguments");
+    gain_pick_bwd_bwd_kernel<<<dim3((unsigned)((n * C + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+        ddx, ldd, dy, x, ldx, labels, ddy, dx2, n, C, ratio, sigmoid);
+    MSSR_LAUNCH_OK("gain_pick_bwd_bwd");
 }

@@ -800,6 +800,65 @@ class second_order:
         _tls.second_order = self.prev
 
 
+class _GainPickBwd(Function):
+    """dx = onehot(labels) * dy * f'(x): the backward of _GainPick as an op of its own, so that graphs built with
+    create_graph (the gradient penalty) can differentiate through it."""
+
+    @staticmethod
+    def forward(ctx, dy, x, labels, ratio, sig):
+        n, C = x.shape
+        dyc = dy.to(torch.float32).contiguous()
+        dx = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        L.check(L.load().mssr_gain_pick_bwd(dyc.data_ptr(), x.data_ptr(), x.stride(0), labels.data_ptr(), dx.data_ptr(), n, C,
+                                            ratio, sig, L.stream()), "gain_pick_bwd")
+        ctx.save_for_backward(dyc, x, labels)
+        ctx.ratio, ctx.sig = ratio, sig
+        return dx
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, ddx):
+        dy, x, labels = ctx.saved_tensors
+        n, C = x.shape
+        if ddx.stride(1) != 1 or ddx.dtype != torch.float32:
+            ddx = ddx.to(torch.float32).contiguous()
+        ddy = torch.empty(n, dtype=torch.float32, device=x.device)
+        dx2 = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        L.check(L.load().mssr_gain_pick_bwd_bwd(ddx.data_ptr(), ddx.stride(0), dy.data_ptr(), x.data_ptr(), x.stride(0),
+                                                labels.data_ptr(), ddy.data_ptr(), dx2.data_ptr(), n, C, ctx.ratio, ctx.sig,
+                                                L.stream()), "gain_pick_bwd_bwd")
+        return ddy, dx2, None, None, None
+
+
+class _GainPick(Function):
+    @staticmethod
+    def forward(ctx, x, labels, ratio, sig):
+        n, C = x.shape
+        out = torch.empty(n, dtype=torch.float32, device=x.device)
+        L.check(L.load().mssr_gain_pick_fwd(x.data_ptr(), x.stride(0), labels.data_ptr(), out.data_ptr(), n, C, ratio, sig,
+                                            L.stream()), "gain_pick_fwd")
+        ctx.save_for_backward(x, labels)
+        ctx.ratio, ctx.sig = ratio, sig
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, labels = ctx.saved_tensors
+        return _GainPickBwd.apply(dy, x, labels, ctx.ratio, ctx.sig), None, None, None
+
+
+def gain_pick(logits, labels, ratio=1.0, sigmoid=True):
+    """The critic's gain at each row's label: ratio * sigmoid(logits[i, labels[i]]) (or the raw logit), float32 [n].
+    One launch for the reference's sigmoid gain + cal_disc_loss pick (onmt/trainer_wgan_wh.py:402-416, :1192-1200);
+    twice differentiable."""
+    L.require_cuda(logits, labels)
+    if logits.dim() != 2 or labels.shape != logits.shape[:1] or labels.dtype != torch.int64:
+        raise ValueError("gain_pick: logits [n, C] and int64 labels [n] expected (got %s, %s %s)" % (
+            tuple(logits.shape), tuple(labels.shape), labels.dtype))
+    x = logits if logits.dtype == torch.float32 and logits.stride(1) == 1 else logits.float().contiguous()
+    return _GainPick.apply(x, labels.contiguous(), float(ratio), int(bool(sigmoid)))
+
+
 class _GpPenalty(Function):
     """lamb * mean over the masked rows of (||g_row|| - k)^2 in one launch (csrc/elementwise.hip, mssr_gp_penalty_*).
     g [n0, n1, d] with any row strides (d contiguous), mask Bool [n0, n1] with any strides.  g carries the graph of

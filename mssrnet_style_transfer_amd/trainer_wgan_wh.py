@@ -148,6 +148,20 @@ class Trainer:
             return torch.sigmoid(logits) * self.cfg.gain_ratio
         raise ValueError("unsupported force_positive_gain_mode: %s" % mode)
 
+    def _pick(self, logits, labels, mode):
+        """cal_disc_loss(self._gain(logits, mode), labels) in one launch (ops.gain_pick, twice differentiable)."""
+        if mode not in ("normal", "sigmoid"):
+            raise ValueError("unsupported force_positive_gain_mode: %s" % mode)
+        idx = labels if torch.is_tensor(labels) else torch.as_tensor(labels, device=logits.device)
+        return ops.gain_pick(logits, idx, self.cfg.gain_ratio, mode == "sigmoid")
+
+    def _style_logits(self, x, lengths):
+        """The style critic's raw logits (fp32 island, see _call_style_discriminator)."""
+        if self.cfg.style_critic_fp32 and ops.compute_dtype() != torch.float32:
+            with ops.compute_as(torch.float32):
+                return self.style_discriminator(x, lengths)
+        return self.style_discriminator(x, lengths)
+
     def _call_text_discriminator(self, x, lengths):
         return self._gain(self.text_discriminator(x, lengths), self.cfg.gain_mode_t)
 
@@ -334,8 +348,7 @@ class Trainer:
         with ops.second_order():
             emb = torch.cat([critic.encoder.embeddings(vocab_target),
                              critic.encoder.embeddings(torch.cat([probs.to(inter.dtype), inter], 1))], 1)
-            gains = self._gain(critic.forward_embedded(emb, text_len.repeat(3)), cfg.gain_mode_t)
-            picked = cal_disc_loss(gains, labels.repeat(3))
+            picked = self._pick(critic.forward_embedded(emb, text_len.repeat(3)), labels.repeat(3), cfg.gain_mode_t)
         err = picked[2 * B:]
         g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
         gp = self._penalty(g.transpose(0, 1), text_len, vocab_target.size(0), cfg.wgan_text_k, cfg.wgan_text_lamb)
@@ -352,8 +365,8 @@ class Trainer:
         alpha = _to_device_async(alpha_s, real)
         inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
         with ops.second_order():
-            picked = cal_disc_loss(self._call_style_discriminator(torch.cat([real, fake, inter]), lengths.repeat(3)),
-                                   labels.repeat(3))
+            picked = self._pick(self._style_logits(torch.cat([real, fake, inter]), lengths.repeat(3)), labels.repeat(3),
+                                cfg.gain_mode_s)
         err = picked[2 * B:]
         g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
         gp = self._penalty(g, lengths, real.size(1), cfg.wgan_style_k, cfg.wgan_style_lamb)
@@ -417,10 +430,10 @@ class Trainer:
             rep2, probs, sprobs, _ = self._generator_forward_batched(labels, real_src, real_len, tgt_len)
         seq_lens, _ = dec_output_length(probs, cfg)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
-        gain_t = cal_disc_loss(self._call_text_discriminator(probs, lens), desired_list).mean()
+        gain_t = self._pick(self.text_discriminator(probs, lens), desired_list, cfg.gain_mode_t).mean()
         with torch.no_grad():
             acc = self.classifier(probs, lens).argmax(-1).eq(desired).float().mean()
-        gain_s = cal_disc_loss(self._call_style_discriminator(rep2.transpose(0, 1), real_len), desired_list).mean()
+        gain_s = self._pick(self._style_logits(rep2.transpose(0, 1), real_len), desired_list, cfg.gain_mode_s).mean()
         vl = self.vocab_loss_from_probs(sprobs, vocab_target.contiguous().view(-1), B)
         total = vl - cfg.text_ap_scale * gain_t - cfg.style_ap_scale * gain_s
         self._arm(self.style_generator, self.model)

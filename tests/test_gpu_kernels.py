@@ -943,3 +943,36 @@ def test_gp_penalty_kernel(ops, dtype, n0, n1, d, strided):
     assert float(full.grad[1, -1].abs().max()) == 0.0 and float(full.grad[:, n1:][0, 0].abs().max() if strided else full.grad[0, 0].abs().max()) == 0.0
     with pytest.raises(RuntimeError):
         ops.gp_penalty(g.detach().cpu(), mask.cpu(), k, lamb)   # no CPU path
+
+
+@pytest.mark.parametrize("sigmoid", [True, False])
+def test_gain_pick_twice_differentiable(ops, sigmoid):
+    """ops.gain_pick = the critics' sigmoid gain followed by cal_disc_loss's per-row pick
+    (trainer_wgan_wh.py:402-416, :1192-1200) in one launch, against torch in float64: value, gradient, and the
+    gradient of a function of the gradient (what the WGAN-GP penalty takes)."""
+    torch.manual_seed(7)
+    n, C, ratio = 240, 4, 1.5
+    base = torch.randn(n, C + 2, device="cuda")
+    labels = torch.randint(0, C, (n,), device="cuda")
+    w = torch.randn(n, device="cuda")
+
+    def run(x, pick):
+        z = (x * x).cumsum(1) * 0.3 + x                          # something upstream with curvature
+        picked = pick(z)
+        g, = torch.autograd.grad(picked, x, w.to(picked.dtype), create_graph=True)
+        loss = (g ** 2).sum() + picked.sum()
+        loss.backward()
+        return picked.detach(), g.detach(), x.grad
+
+    x32 = base[:, :C].clone().requires_grad_(True)               # contiguous copy; strided logits are covered below
+    got = run(x32, lambda z: ops.gain_pick(z, labels, ratio, sigmoid))
+    x64 = base[:, :C].double().requires_grad_(True)
+    ref = lambda z: ((torch.sigmoid(z) * ratio) if sigmoid else z).gather(1, labels.view(-1, 1)).squeeze(1)  # noqa: E731
+    want = run(x64, ref)
+    for a, b, name in zip(got, want, ("picked", "first derivative", "second-order gradient")):
+        assert_close(a, b.float(), 2e-5, "gain_pick " + name)
+    strided = ops.gain_pick(base[:, :C], labels, ratio, sigmoid)  # row stride C + 2
+    assert_close(strided, ref(base[:, :C].double()).float(), 2e-5, "gain_pick strided")
+    bad = labels.clone()
+    bad[3] = C
+    assert bool(torch.isnan(ops.gain_pick(base[:, :C], bad, ratio, sigmoid)[3]))
