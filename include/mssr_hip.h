@@ -319,6 +319,7 @@ typedef struct {
     float p_drop;                 /* 0 = no dropout */
     uint64_t seed;
     int dtype;
+    int drop_b0;                  /* sentences b < drop_b0 are NOT dropped (eval-mode rows batched with training rows) */
 } mssr_attn_desc;
 int mssr_attention_fits(int Lq, int Lk, int dh, int dtype, int backward);
 /* ctx row (b, i) at ctx + b*ctx_bs + i*ctx_ls, head h at column h*dh; probs (may be NULL) receives the
@@ -377,6 +378,11 @@ typedef struct {
                                    * layer_norm, final_linear, feed_forward.layer_norm, w_2) */
     void* dactF;                  /* [n_layers][R, ff]    gradient of the w_1 output */
     void* dctx;                   /* [R, d] scratch */
+    /* Two passes over the same weights in ONE call (no reference counterpart: the reference encodes the critics'
+     * inputs in eval mode under no_grad, onmt/trainer_wgan_wh.py:530-535, and the generator phase's in train mode,
+     * :898-968, one after the other): sentences [0, eval_rows) run WITHOUT dropout whatever `training` says.  Their
+     * rows take part in the backward like any other (the caller feeds zero gradient for them).  0 = plain. */
+    int eval_rows;
 } mssr_encoder_plan;
 int mssr_encoder_fwd(const mssr_encoder_plan* plan, void* stream);
 /* Leaves the gradient of every Linear output in the d* slabs; the caller contracts them with the saved

@@ -56,7 +56,8 @@ class EncoderPlan(Structure):
                 + [(n, c_void_p) for n in ("lnF_g", "lnF_b", "mask", "X", "out", "qkv", "actD", "actF", "stats",
                                            "gemm_ws")]
                 + [("gemm_ws_bytes", c_int64)]
-                + [(n, c_void_p) for n in ("dout", "dX", "dqkv", "dactD", "dactF", "dctx")])
+                + [(n, c_void_p) for n in ("dout", "dX", "dqkv", "dactD", "dactF", "dctx")]
+                + [("eval_rows", c_int)])
 
 
 class DecodePlan(Structure):
@@ -90,7 +91,7 @@ class AttnDesc(Structure):
                 ("B", c_int), ("H", c_int), ("Lq", c_int), ("Lk", c_int), ("dh", c_int),
                 ("q_bs", c_int64), ("q_ls", c_int64), ("k_bs", c_int64), ("k_ls", c_int64),
                 ("v_bs", c_int64), ("v_ls", c_int64), ("mask_bs", c_int64), ("mask_qs", c_int64),
-                ("p_drop", c_float), ("seed", c_uint64), ("dtype", c_int)]
+                ("p_drop", c_float), ("seed", c_uint64), ("dtype", c_int), ("drop_b0", c_int)]
 
 
 class PackJob(Structure):

@@ -181,6 +181,7 @@ static int fa_check(const char* who, const mssr_attn_desc* d) {
     MSSR_REQUIRE((int64_t)d->B * d->H <= 0x7fffffff, "%s: too many (sentence, head) pairs", who);
     MSSR_REQUIRE(d->q && d->k && d->v, "%s: null operand", who);
     MSSR_REQUIRE(d->p_drop >= 0.f && d->p_drop < 1.f, "%s: p_drop out of [0,1)", who);
+    MSSR_REQUIRE(d->drop_b0 >= 0 && d->drop_b0 <= d->B, "%s: drop_b0 outside [0, B]", who);
     const size_t es = dsize(d->dtype);
     const int64_t strides[] = {d->q_bs, d->q_ls, d->k_bs, d->k_ls, d->v_bs, d->v_ls};
     for (int64_t st : strides) MSSR_REQUIRE(st % 4 == 0, "%s: strides must be multiples of 4 elements", who);
@@ -196,6 +197,7 @@ static void fa_args(const mssr_attn_desc* d, AttnArgs& a) {
     a.mask_bs = d->mask_bs; a.mask_qs = d->mask_qs;
     a.scale = 1.0f / sqrtf((float)d->dh);
     a.p_drop = d->p_drop; a.seed = d->seed;
+    a.drop_b0 = d->drop_b0;
 }
 
 }  // namespace mssr

@@ -13,10 +13,11 @@ struct AttnArgs {
     int64_t q_bs, q_ls, k_bs, k_ls, v_bs, v_ls, mask_bs, mask_qs;
     float scale, p_drop;
     uint64_t seed;
+    int drop_b0;        // sentences below it are not dropped
 };
 
 __device__ __forceinline__ float fa_keep(const AttnArgs& a, int bh, int i, int t) {
-    if (a.p_drop <= 0.f) return 1.0f;
+    if (a.p_drop <= 0.f || bh / a.H < a.drop_b0) return 1.0f;
     const uint32_t thr = drop_thr16(a.p_drop);
     return keep16(a.seed, ((uint64_t)bh * a.Lq + i) * FA_KSTRIDE + t, thr) ? 1.0f / (1.0f - a.p_drop) : 0.f;
 }

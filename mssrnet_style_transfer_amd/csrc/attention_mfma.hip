@@ -191,7 +191,7 @@ __global__ __launch_bounds__(256) void attn_mfma_fwd_kernel(const AttnArgs a, bf
             for (int u = 0; u < 2; ++u) {
                 const int t0 = 32 * c + 16 * u + 4 * g;
                 float keep[4] = {1.f, 1.f, 1.f, 1.f};
-                if (a.p_drop > 0.f) fm_keep4(a, thr, inv, bh, ic, t0, keep);
+                if (a.p_drop > 0.f && b >= a.drop_b0) fm_keep4(a, thr, inv, bh, ic, t0, keep);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const bf16 pb = (bf16)s[2 * c + u][r];            // the probability as the reference stores it
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const AttnArgs a, co
 #pragma unroll
         for (int t = 0; t < 2 * NC; ++t) {
             float keep[4] = {1.f, 1.f, 1.f, 1.f};
-            if (a.p_drop > 0.f) fm_keep4(a, thr, inv, bh, ic, 16 * t + 4 * g, keep);
+            if (a.p_drop > 0.f && b >= a.drop_b0) fm_keep4(a, thr, inv, bh, ic, 16 * t + 4 * g, keep);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float p = (float)(bf16)s[t][r];
@@ -368,7 +368,7 @@ __global__ __launch_bounds__(256) void attn_mfma_bwd_kernel(const AttnArgs a, co
                     const float v = masked ? -1e18f : sa[r] * a.scale;
                     float p = live ? (float)(bf16)(__expf(v - m4[r]) * l4[r]) : 0.f;
                     float keep = 1.f;
-                    if (a.p_drop > 0.f)
+                    if (a.p_drop > 0.f && b >= a.drop_b0)
                         keep = keep16(a.seed, ((uint64_t)bh * a.Lq + (live ? i : 0)) * FA_KSTRIDE + tc, thr) ? inv : 0.f;
                     pl[u][r] = p * keep;
                     dl[u][r] = masked ? 0.f : p * (da[r] * keep - r4[r]) * a.scale;

@@ -75,6 +75,7 @@ static void ds_self_desc(const mssr_decstack_plan* p, const StackGeo& G, int l, 
     a.mask_bs = (int64_t)p->T * p->T; a.mask_qs = p->T;
     a.p_drop = p_attn; a.seed = ds_seed(p, l, 0);
     a.dtype = p->dtype;
+    a.drop_b0 = 0;
 }
 
 // context attention: queries of layer l against its keys | values inside mem_kv (columns [l*2d, l*2d + 2d))
@@ -92,6 +93,7 @@ static void ds_ctx_desc(const mssr_decstack_plan* p, const StackGeo& G, int l, f
     a.mask_bs = p->Ls; a.mask_qs = 0;
     a.p_drop = p_attn; a.seed = ds_seed(p, l, 2);
     a.dtype = p->dtype;
+    a.drop_b0 = 0;
 }
 
 }  // namespace mssr

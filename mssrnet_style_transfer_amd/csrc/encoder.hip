@@ -31,6 +31,7 @@ static int enc_check(const mssr_encoder_plan* p, bool backward, const char* who)
     MSSR_REQUIRE(p->layers && p->lnF_g && p->lnF_b && p->X && p->out && p->qkv && p->actD && p->actF && p->stats,
                  "%s: null buffer in plan", who);
     MSSR_REQUIRE(p->p_drop >= 0.f && p->p_drop < 1.f && p->p_attn >= 0.f && p->p_attn < 1.f, "%s: bad dropout", who);
+    MSSR_REQUIRE(p->eval_rows >= 0 && p->eval_rows <= p->B, "%s: eval_rows outside [0, B]", who);
     const int dh = p->d / p->heads;
     MSSR_REQUIRE(mssr_attention_fits(p->L, p->L, dh, p->dtype, backward ? 1 : 0),
                  "%s: L=%d, dh=%d is beyond the fused attention kernel", who, p->L, dh);
@@ -81,6 +82,7 @@ static void enc_attn_desc(const mssr_encoder_plan* p, const EncGeo& G, int l, fl
     a.mask_bs = p->L; a.mask_qs = 0;
     a.p_drop = p_attn; a.seed = enc_seed(p, l, 0);
     a.dtype = p->dtype;
+    a.drop_b0 = p->eval_rows;
 }
 
 }  // namespace mssr
@@ -95,6 +97,7 @@ extern "C" int mssr_encoder_fwd(const mssr_encoder_plan* p, void* stream) {
     const int d = G.d, ff = G.ff, NL = G.NL;
     const float pd = p->training ? p->p_drop : 0.f, pa = p->training ? p->p_attn : 0.f;
     const bool fuse = p->fuse_ln != 0;
+    const int64_t row0 = (int64_t)p->eval_rows * p->L;        // rows below it (eval-mode sentences) skip dropout
     int rc;
     for (int l = 0; l < NL; ++l) {
         const mssr_enc_layer& L = p->layers[l];
@@ -117,23 +120,23 @@ extern "C" int mssr_encoder_fwd(const mssr_encoder_plan* p, void* stream) {
         enc_attn_desc(p, G, l, pa, a);
         if ((rc = mssr_attention_fwd(&a, ctx, (int64_t)p->L * d, d, nullptr, c.s))) return rc;
         if ((rc = gemm_nt(c, ctx, d, L.w_o, d, h, d, R, d, d, L.b_o, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          enc_seed(p, l, 1))))
+                          enc_seed(p, l, 1), nullptr, nullptr, nullptr, row0)))
             return rc;
         // --- feed forward block
         if (fuse) {
             if ((rc = gemm_nt(c, h, d, L.wg_1, d, inter, ff, R, ff, d, L.bf_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                              enc_seed(p, l, 2), L.cs_1, G.stat(2 * l + 1, 0), G.stat(2 * l + 1, 1))))
+                              enc_seed(p, l, 2), L.cs_1, G.stat(2 * l + 1, 0), G.stat(2 * l + 1, 1), row0)))
                 return rc;
         } else {
             if ((rc = mssr_layernorm_fwd(h, L.lnf_g, L.lnf_b, n2, G.stat(2 * l + 1, 0), G.stat(2 * l + 1, 1), R, d, 1e-6f,
                                          c.dt, c.s)))
                 return rc;
             if ((rc = gemm_nt(c, n2, d, L.w_1, d, inter, ff, R, ff, d, L.b_1, 1, nullptr, 0, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                              enc_seed(p, l, 2))))
+                              enc_seed(p, l, 2), nullptr, nullptr, nullptr, row0)))
                 return rc;
         }
         if ((rc = gemm_nt(c, inter, ff, L.w_2, ff, G.X(l + 1), d, R, d, ff, L.b_2, 0, h, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
-                          enc_seed(p, l, 3))))
+                          enc_seed(p, l, 3), nullptr, nullptr, nullptr, row0)))
             return rc;
     }
     return mssr_layernorm_fwd(G.X(NL), p->lnF_g, p->lnF_b, p->out, G.stat(2 * NL, 0), G.stat(2 * NL, 1), R, d, 1e-6f,

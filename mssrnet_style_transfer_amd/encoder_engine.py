@@ -118,7 +118,7 @@ def get_pack(enc, params):
 
 
 class _Spec:
-    __slots__ = ("pack", "B", "L", "heads", "training", "p_drop", "p_attn", "seed", "mask", "save")
+    __slots__ = ("pack", "B", "L", "heads", "training", "p_drop", "p_attn", "seed", "mask", "save", "eval_rows")
 
 
 class _EncoderStack(Function):
@@ -140,6 +140,7 @@ class _EncoderStack(Function):
         plan.save, plan.training = int(spec.save), int(spec.training)
         plan.fuse_ln = int(pk.fuse_ln and not spec.save and R <= 8192)      # the K-split GEMM (LN prologue) takes <= 8192 rows
         plan.p_drop, plan.p_attn, plan.seed = spec.p_drop, spec.p_attn, spec.seed
+        plan.eval_rows = spec.eval_rows
         plan.layers = pk.layers
         plan.lnF_g, plan.lnF_b = pk.lnF_g.data_ptr(), pk.lnF_b.data_ptr()
         plan.mask = L.ptr(spec.mask)
@@ -197,10 +198,13 @@ class _EncoderStack(Function):
         return tuple(out)
 
 
-def run_stack(enc, x, pad_mask):
+def run_stack(enc, x, pad_mask, eval_rows=0):
     """LayerNorm(layers(x)) for x [B, L, d] (any strides) and pad_mask Bool/uint8 [B, L] (True = padding key),
     or None when the engine does not apply (second-order graph, shapes beyond the fused attention
-    kernel, unequal dropout rates): the caller then loops over the modules."""
+    kernel, unequal dropout rates): the caller then loops over the modules.  eval_rows: sentences [0, eval_rows)
+    run without dropout even in train mode (mssr_encoder_plan.eval_rows)."""
+    if not 0 <= eval_rows <= x.shape[0]:
+        raise ValueError("run_stack: eval_rows %d outside [0, %d]" % (eval_rows, x.shape[0]))
     if ops.second_order_active() or len(enc.transformer) == 0:
         return None
     layer0 = enc.transformer[0]
@@ -224,6 +228,7 @@ def run_stack(enc, x, pad_mask):
     spec.training = bool(layer0.training)
     spec.p_drop, spec.p_attn = p_drop, float(layer0.self_attn.dropout.p)
     spec.seed = ops.next_seed()
+    spec.eval_rows = int(eval_rows)
     m = pad_mask
     if m is not None:
         m = m.contiguous()

@@ -57,17 +57,22 @@ class TransformerEncoder(EncoderBase):
                    opt.attention_dropout[0] if type(opt.attention_dropout) is list else opt.attention_dropout,
                    embeddings, opt.max_relative_positions)
 
-    def forward(self, src, lengths=None):
-        """src: Long [L, B, 1] or float [L, B, V]; lengths Long [B]."""
+    def forward(self, src, lengths=None, eval_rows=0):
+        """src: Long [L, B, 1] or float [L, B, V]; lengths Long [B].  eval_rows (no reference counterpart): the first
+        eval_rows sentences are encoded without dropout even in train mode."""
         self._check_args(src, lengths)
+        if eval_rows:
+            return self.forward_embedded(self.embeddings(src, eval_rows=eval_rows), lengths, eval_rows)
         return self.forward_embedded(self.embeddings(src), lengths)
 
-    def forward_embedded(self, emb, lengths):
+    def forward_embedded(self, emb, lengths, eval_rows=0):
         """The encoder behind its embedding layer: emb [L, B, d] (``self.embeddings`` of ids or of soft words, possibly
         of several inputs concatenated along the batch) -> (emb, memory_bank, lengths).  No reference counterpart as a
         method: it is the body of onmt/encoders/transformer.py:118-129 after the embedding call."""
         pad = ~sequence_mask(lengths, max_len=emb.size(0))                 # [B, L], True = padding
-        out = run_stack(self, emb.transpose(0, 1), pad)                    # all layers + final LN: one C call
+        out = run_stack(self, emb.transpose(0, 1), pad, eval_rows)         # all layers + final LN: one C call
+        if out is None and eval_rows:
+            raise RuntimeError("TransformerEncoder: eval_rows needs the encoder engine (not available for this graph / shape)")
         if out is None:                                                    # second-order graphs, long sequences
             out = emb.transpose(0, 1).contiguous()
             mask = pad.unsqueeze(1)

@@ -95,7 +95,9 @@ class Embeddings(nn.Module):
             n = min(self.word_vec_size, pretrained.size(1))
             self.word_lut.weight.data[:, :n] = pretrained[:, :n]
 
-    def forward(self, source, step=None):
+    def forward(self, source, step=None, eval_rows=0):
+        """eval_rows (no reference counterpart): sentences [0, eval_rows) of the batch are embedded without dropout
+        even in train mode (eval-mode rows batched with training rows, see Trainer.train_wgan_step)."""
         pe = self.make_embedding[1]
         weight = self.word_lut.weight
         s = math.sqrt(pe.dim)
@@ -105,6 +107,8 @@ class Embeddings(nn.Module):
             out = ops.scale_add_pe(emb, pe.table(), step, s)
         else:                                                    # fused lookup * sqrt(d) + pe
             out = ops.embed_pe(source[:, :, 0], weight, pe.table(), step, s, self.word_padding_idx)
+        if eval_rows and pe.training and pe.dropout.p > 0:
+            return torch.cat([out[:, :eval_rows], ops.dropout(out[:, eval_rows:].contiguous(), pe.dropout.p, True)], 1)
         return ops.dropout(out, pe.dropout.p, pe.training)
 
     def update_dropout(self, dropout):

@@ -108,15 +108,18 @@ class StyleGenerator2(nn.Module):
         self.style_cls = nn.Embedding(num_styles, h_size)
         self.encoder = encoder
 
-    def forward(self, desired_style, src, src_lengths):
+    def forward(self, desired_style, src, src_lengths, eval_rows=0):
+        """eval_rows (no reference counterpart): the first eval_rows sentences run without dropout in train mode."""
         enc = self.encoder
         enc._check_args(src, src_lengths)
-        emb = enc.embeddings(src)
+        emb = enc.embeddings(src, eval_rows=eval_rows) if eval_rows else enc.embeddings(src)
         # the style token row is neither scaled by sqrt(d) nor position-encoded (quirk 10)
         cls_emb = self.style_cls(desired_style).to(emb.dtype)
         x = torch.cat((cls_emb.unsqueeze(0), emb), 0).transpose(0, 1)
         pad = ~sequence_mask(src_lengths + 1, max_len=src.size(0) + 1)
-        out = run_stack(enc, x, pad)
+        out = run_stack(enc, x, pad, eval_rows)
+        if out is None and eval_rows:
+            raise RuntimeError("StyleGenerator2: eval_rows needs the encoder engine (not available for this graph / shape)")
         if out is None:
             out = x.contiguous()
             mask = pad.unsqueeze(1)

@@ -221,11 +221,16 @@ class Trainer:
             _, memory_bank, _ = self.classifier.encoder(real_src, real_len)
         return memory_bank.detach()
 
-    def _gen_style_represents(self, desired, real_src, real_len):
+    def _gen_style_represents(self, desired, real_src, real_len, eval_rows=0):
+        if eval_rows:
+            return self.style_generator(desired, real_src, real_len, eval_rows=eval_rows)
         return self.style_generator(desired, real_src, real_len)
 
-    def _encode(self, real_src, real_len, style_rep):
-        enc_state, memory_bank, lengths = self.model.encoder(real_src, real_len)
+    def _encode(self, real_src, real_len, style_rep, eval_rows=0):
+        if eval_rows:
+            enc_state, memory_bank, lengths = self.model.encoder(real_src, real_len, eval_rows=eval_rows)
+        else:
+            enc_state, memory_bank, lengths = self.model.encoder(real_src, real_len)
         return enc_state, self.model.bond_layer(memory_bank, style_rep), lengths
 
     def _self_reconstruct(self, real_src, real_len, tgt, style_rep):
@@ -383,32 +388,35 @@ class Trainer:
                         derive=lambda d: dict(T_cost=d["TF_gain"] - d["TR_gain"] + d["T_gp"], T_Wgap=d["TR_gain"] - d["TF_gain"],
                                        S_cost=d["SF_gain"] - d["SR_gain"] + d["S_gp"], S_Wgap=d["SR_gain"] - d["SF_gain"]))
 
-    def _generator_forward_batched(self, labels, real_src, real_len, tgt_len, eval_prefix=None):
+    def _generator_forward_batched(self, labels, real_src, real_len, tgt_len, with_eval=False):
         """Style representations, bonded encoder states and ONE soft decode for both halves of the generator phase
         (adversarial text: desired style, tgt_len + 10 steps; self-style text: own style, tgt_len steps).
-        ``eval_prefix`` = (memory bank [Ls, B, d], lengths) of sentences to decode in the same sweep in eval mode
-        without gradient (the critics' fake text): returns their probabilities as well."""
+        ``with_eval``: the critics' inputs -- the own-style representation and the text decoded from it, which
+        train_discriminator computes in eval mode under no_grad (:530-535, :571) -- ride along as B more sentences at
+        the front of every call (``eval_rows``: no dropout, no gradient): returns them as well."""
         cfg = self.cfg
         B = real_len.numel()
         desired = 1 - labels
         max_dec_steps = tgt_len + cfg.max_extra_dec_steps
-        rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1),
-                                             real_len.repeat(3))
-        rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
-        src2, len2 = real_src.repeat(1, 2, 1), real_len.repeat(2)
-        enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep, rep3], 1))
-        fake = None
-        if eval_prefix is None:
+        if not with_eval:
+            rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1),
+                                                 real_len.repeat(3))
+            rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
+            src2, len2 = real_src.repeat(1, 2, 1), real_len.repeat(2)
+            enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep, rep3], 1))
             self.model.decoder.init_state(src2, mem, enc_state)
             probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
-        else:
-            mem_e, len_e = eval_prefix
-            E = len_e.numel()
-            self.model.decoder.init_state(real_src.repeat(1, 3, 1), None, None)
-            both = soft_decode(self.model, cfg, torch.cat([mem_e.to(mem.dtype), mem], 1), torch.cat([len_e, len2]),
-                               max_dec_steps, eval_rows=E)
-            fake, probs_all = both[:tgt_len, :E].detach(), both[:, E:]
-        return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], fake
+            return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], None, None
+        rep_all = self._gen_style_represents(torch.cat([labels, desired, desired, labels]), real_src.repeat(1, 4, 1),
+                                             real_len.repeat(4), eval_rows=B)
+        rep_d = rep_all[:, :B].detach()
+        rep, rep2, rep3 = rep_all[:, B:2 * B], rep_all[:, 2 * B:3 * B], rep_all[:, 3 * B:]
+        src3, len3 = real_src.repeat(1, 3, 1), real_len.repeat(3)
+        _, mem, _ = self._encode(src3, len3, torch.cat([rep_d, rep, rep3], 1), eval_rows=B)
+        self.model.decoder.init_state(src3, None, None)
+        both = soft_decode(self.model, cfg, mem, len3, max_dec_steps, eval_rows=B)     # no gradient into mem[:, :B]
+        fake, probs_all = both[:tgt_len, :B].detach(), both[:, B:]
+        return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], fake, rep_d
 
     def _train_generator_batched(self, batch, _shared=None):
         """train_generator with its independent pieces batched (cfg.batch_generator_phase): the reference
@@ -427,7 +435,7 @@ class Trainer:
         if _shared is not None:
             rep2, probs, sprobs = _shared
         else:
-            rep2, probs, sprobs, _ = self._generator_forward_batched(labels, real_src, real_len, tgt_len)
+            rep2, probs, sprobs, _, _ = self._generator_forward_batched(labels, real_src, real_len, tgt_len)
         seq_lens, _ = dec_output_length(probs, cfg)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
         gain_t = self._pick(self.text_discriminator(probs, lens), desired_list, cfg.gain_mode_t).mean()
@@ -454,19 +462,16 @@ class Trainer:
             return self.train_discriminator(batch), self.train_generator(batch)
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
         tgt_len = vocab_target.size(0)
-        # generator side in eval mode: what train_discriminator computes under no_grad (:530-535)
-        self.style_generator.eval()
-        self.model.eval()
-        with torch.no_grad():
-            rep_d = self._gen_style_represents(labels, real_src, real_len)
-            _, mem_d, _ = self._encode(real_src, real_len, rep_d)
-        # generator side in train mode: the forward half of train_generator, decode shared with the rows above
+        # generator side in train mode: the forward half of train_generator.  What train_discriminator computes in
+        # eval mode under no_grad (:530-535: own-style representation -> bonded encoder states -> decoded text) rides
+        # along as the first B sentences of the same style-generator, encoder and decode calls (eval_rows: those
+        # sentences skip every dropout site and receive no gradient)
         self.style_generator.train()
         self.model.train()
         self.style_generator_optim.zero_grad()
         self.model_optim.zero_grad()
-        rep2, probs, sprobs, fake = self._generator_forward_batched(labels, real_src, real_len, tgt_len,
-                                                                   eval_prefix=(mem_d, real_len))
+        rep2, probs, sprobs, fake, rep_d = self._generator_forward_batched(labels, real_src, real_len, tgt_len,
+                                                                          with_eval=True)
         d_log = self.train_discriminator(batch, _shared=(rep_d, fake))
         g_log = self.train_generator(batch, _shared=(rep2, probs, sprobs))
         return d_log, g_log

@@ -122,6 +122,51 @@ def test_encoder_engine_dropout_backward_replays_masks(ops):
     assert abs(an - fd) <= 6e-2 * max(abs(fd), 1e-3), (an, fd)
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_encoder_mixed_eval_train_rows(ops, dtype):
+    """eval_rows sentences of a train-mode encoder call (mssr_encoder_plan.eval_rows: the critics' eval-mode inputs
+    batched with the generator phase's, Trainer.train_wgan_step) must come out as an eval-mode pass gives them --
+    every dropout site (embedding, attention probabilities, both residual sites, FFN) skipped for those sentences only
+    -- while the others are dropped, and the backward must replay exactly the masks the forward drew."""
+    ops.set_compute_dtype(dtype)
+    cfg = MSSRConfig.small(dropout=0.3, attention_dropout=0.3)
+    E, G, Ls = 3, 4, 6
+    # bf16 with 32-wide heads: the matrix-core attention kernels; fp32: the scalar ones
+    enc, soft, lens = make(cfg, (2, 4, 16) if dtype == torch.float32 else (2, 2, 32), E + G, Ls, seed=5)
+    lens = torch.tensor([6, 3, 5, 6, 2, 4, 6], device="cuda")
+    ids = torch.randint(9, cfg.vocab_size, (Ls, E + G, 1), device="cuda")
+    enc.eval()
+    with torch.no_grad():
+        want_eval = enc(ids[:, :E], lens[:E])[1]
+        all_eval = enc(ids, lens)[1]
+    enc.train()
+
+    def f(x, **kw):
+        ops._state["seed_counter"] = 777
+        return enc(x, lens, **kw)[1]
+
+    with torch.no_grad():
+        both = f(ids, eval_rows=E)
+        assert torch.equal(f(ids, eval_rows=E), both), "same seed must give the same masks"
+    tol = 1e-5 if dtype == torch.float32 else 2e-2      # another row count takes other GEMM kernels (summation order)
+    assert_close(both[:, :E].float(), want_eval.float(), tol, "eval rows of the mixed call")
+    assert float((both[:, E:].float() - all_eval[:, E:].float()).abs().max()) > 1e-3       # the others ARE dropped
+    if dtype != torch.float32:
+        return
+    # backward on soft inputs (differentiable w.r.t. the input): embedding dropout is outside the engine
+    w = torch.randn(Ls, E + G, 64, device="cuda")
+    w[:, :E] = 0                                        # the eval sentences' outputs are used without gradient
+    s = soft.clone().requires_grad_(True)
+    out = f(s, eval_rows=E)
+    (out * w).sum().backward()
+    assert float(s.grad[:, :E].abs().max()) == 0.0
+    v = s.grad / s.grad.norm() * 3e-3
+    an = float((s.grad * v).sum())
+    with torch.no_grad():
+        fd = float(((f(soft + v, eval_rows=E).double() - f(soft - v, eval_rows=E).double()) * w.double()).sum() / 2)
+    assert abs(an - fd) <= 6e-2 * max(abs(fd), 1e-3), (an, fd)
+
+
 def test_encoder_engine_bf16_readme_shapes(ops):
     """12 layers d512 ff1024, bs80 x 16 words in bf16: the engine (K-split GEMMs, LayerNorms folded when
     forward-only, fused attention) against the fp32 modular path, tolerance 2e-2 (north_star)."""

@@ -397,7 +397,10 @@ def test_wgan_step_with_shared_decode_sweep_equals_the_two_phases(ops, golden_ph
     phase's texts: mssr_decode_plan.eval_rows / bwd_row0) against train_discriminator + train_generator called one
     after the other: same logged scalars, same gradients of all four networks, same parameters after the two
     optimizer steps (dropout 0 -> the only differences are the row grouping of the launches and, in bf16, the
-    segmented reduction of the weight-gradient products: mssr_gemm_desc.k_seg_len)."""
+    segmented reduction of the weight-gradient products, mssr_gemm_desc.k_seg_len, and the eval-mode sentences riding
+    through the encoders' saving plan (separate LayerNorm) instead of the forward-only one (LayerNorm folded into the
+    projections): bf16 scalars are held to 2e-3 of the gains' scale (sigmoid gains are O(1); T_Wgap / S_Wgap are
+    differences of two of them)."""
     from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
     ops.set_compute_dtype(dtype)
     try:
@@ -414,12 +417,19 @@ def test_wgan_step_with_shared_decode_sweep_equals_the_two_phases(ops, golden_ph
         ops.set_compute_dtype(torch.float32)
     (d0, g0, n0), (d1, g1, n1) = runs
     tol = 1e-5 if dtype == torch.float32 else 2e-3
+    floor = 1e-3 if dtype == torch.float32 else 1.0
     for k, v in d0.items():
-        assert abs(d1[k] - v) <= tol * max(abs(v), 1e-3), ("D", k, d1[k], v)
+        assert abs(d1[k] - v) <= tol * max(abs(v), floor), ("D", k, d1[k], v)
     for k, v in g0.items():
-        assert abs(g1[k] - v) <= tol * max(abs(v), 1e-3), ("G", k, g1[k], v)
+        assert abs(g1[k] - v) <= tol * max(abs(v), floor), ("G", k, g1[k], v)
     for name in ("text_discriminator", "style_discriminator", "model", "style_generator"):
-        assert_grads(grads_of(n1[name]), {k: g for k, g in grads_of(n0[name]).items()}, 2 * tol, "shared." + name)
+        # bf16: two roundings of the same mathematics (see the docstring) feed five decode steps and the critics'
+        # second-order graph at 64-wide layers: up to 6.4e-2 between the two runs on a critic weight gradient (fp32:
+        # 2e-5, which is what pins the logic); each bf16 run is held to 2e-2 of the reference at README widths
+        # elsewhere (test_gpu_parity_readme.py)
+        assert_grads(grads_of(n1[name]), {k: g for k, g in grads_of(n0[name]).items()},
+                     2 * tol if dtype == torch.float32 else 1e-1, "shared." + name,
+                     floor_rel=1e-5 if dtype == torch.float32 else 3e-2)      # of the network's largest gradient
         # Adam turns a mathematically-zero gradient (rounding noise, e.g. the key-projection bias) into a step of
         # arbitrary sign: every element within 2 lr, as helpers.assert_post_step allows
         for (k, a), (_, b) in zip(n0[name].named_parameters(), n1[name].named_parameters()):
