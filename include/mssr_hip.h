@@ -489,6 +489,16 @@ typedef struct {
      * eval_rows <= bwd_row0. */
     int eval_rows;
     int bwd_row0;
+    /* Teacher-forced sentences in the same sweep (no reference counterpart as one pass: the reference runs the
+     * teacher-forced reconstruction, TransformerDecoder.forward with step = None, onmt/trainer_wgan_wh.py:632-664, and
+     * the soft decodes one after the other): sentences [0, forced_rows) read their inputs of steps 1 .. forced_steps-1
+     * from in_all as the CALLER preset them (one-hot target words; every sentence's step-0 input is preset anyway) --
+     * a step's output does not replace them -- and the backward sends no gradient from those inputs into the previous
+     * step's probabilities.  self_mask (uint8 [B, T], nonzero = this step's key is padding; may be NULL) is the target
+     * padding mask the full-sequence decoder applies to its self attention (onmt/decoders/transformer.py:301-302; the
+     * step-wise reference path has none).  Not with greedy or eval_rows. */
+    int forced_rows, forced_steps;
+    const uint8_t* self_mask;
 } mssr_decode_plan;
 /* One decode step: embeds in_all[step], runs the layers with the cache rows 0..step, writes
  * probs[step] and in_all[step+1]. */

@@ -75,6 +75,10 @@ class MSSRConfig:
     # batched behind the embedding layer and backpropagates the summed objective once (the reference: three forward /
     # backward passes per critic, onmt/trainer_wgan_wh.py:545-620); same losses and gradients up to summation order
     batch_critic_passes: bool = True
+    # not a reference flag: train_reconstruct's teacher-forced decoder pass (onmt/trainer_wgan_wh.py:632-664) runs as
+    # B more sentences of the sweep that decodes its two soft texts (mssr_decode_plan.forced_rows) instead of as a
+    # full-sequence pass of its own; same losses and gradients up to summation order
+    forced_rows_in_sweep: bool = True
     # not a reference flag: the style critic computes in fp32 even when the compute dtype is bf16
     style_critic_fp32: bool = True
 

@@ -747,7 +747,7 @@ template <typename T, int NE, int NT = 256>
 __global__ __launch_bounds__(NT) void vocab_softmax_kernel(const T* __restrict__ logits, int64_t ldl,
                                                            float* __restrict__ probs, int64_t ldp,
                                                            T* __restrict__ copy, int64_t ldc, int n, float inv_t,
-                                                           int greedy, int* __restrict__ ids) {
+                                                           int greedy, int* __restrict__ ids, int copy_row0) {
     constexpr int NW = NT / 64;
     __shared__ float sm[NW];
     __shared__ int si[NW];
@@ -794,7 +794,7 @@ __global__ __launch_bounds__(NT) void vocab_softmax_kernel(const T* __restrict__
         if (c < n) {
             const float p = v[i] * inv;
             probs[(int64_t)row * ldp + c] = p;
-            if (copy) copy[(int64_t)row * ldc + c] = from_f<T>(greedy ? (c == mi ? 1.0f : 0.f) : p);
+            if (copy && row >= copy_row0) copy[(int64_t)row * ldc + c] = from_f<T>(greedy ? (c == mi ? 1.0f : 0.f) : p);
         }
     }
     if (greedy && ids && t == 0) ids[row] = mi;
@@ -944,6 +944,10 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
                  "%s: eval_rows / bwd_row0 outside the batch", who);
     MSSR_REQUIRE((p->eval_rows == 0 && p->bwd_row0 == 0) || (p->n_chunks == 1 && p->eval_rows <= p->bwd_row0),
                  "%s: a mixed eval / train sweep needs n_chunks = 1 and eval_rows <= bwd_row0", who);
+    MSSR_REQUIRE(p->forced_rows >= 0 && p->forced_rows <= p->B && p->forced_steps >= 0 && p->forced_steps <= p->T,
+                 "%s: forced_rows / forced_steps outside the batch / the steps", who);
+    MSSR_REQUIRE(p->forced_rows == 0 || (!p->greedy && p->eval_rows == 0 && p->bwd_row0 == 0),
+                 "%s: teacher-forced sentences cannot be combined with greedy decoding or eval_rows", who);
     return MSSR_OK;
 }
 
@@ -988,6 +992,7 @@ struct Geo {
     }
     const char* mem_kv(int l) const { return at((void*)p->mem_kv, ((int64_t)r0 * Ls * NL + l) * 2 * d, es); }
     const uint8_t* src_mask() const { return p->src_mask + (int64_t)r0 * Ls; }
+    const uint8_t* self_mask() const { return p->self_mask ? p->self_mask + (int64_t)r0 * T : nullptr; }
     char* tmp() const { return at(p->tmp, (int64_t)r0 * d, es); }
     char* logits() const { return at(p->logits, (int64_t)r0 * Vp, es); }
     char* dX(int which) const { return at(p->dX, ((int64_t)which * B + r0) * d, es); }     // two buffers, used in turn
@@ -1049,7 +1054,7 @@ static int step_fwd(const Ctx& c, int step) {
                 return rc;
         }
         DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
-                (int64_t)B * 3 * d, nullptr, 0, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
+                (int64_t)B * 3 * d, G.self_mask(), p->T, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, R, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
                           site_seed(c, step, l, 2), nullptr, nullptr, nullptr, c.eval_rows)))
             return rc;
@@ -1112,15 +1117,17 @@ static int step_fwd(const Ctx& c, int step) {
     }
     float* probs = p->probs + ((int64_t)step * B + G.r0) * p->V;
     void* copy = G.rows(p->in_all, step + 1, p->Vp);                        // in_all has T+1 slots
+    // teacher-forced sentences: their next input was preset by the caller, the step's output must not replace it
+    const int keep_rows = step + 1 < p->forced_steps ? p->forced_rows : 0;
     const int ne = (p->V + 255) / 256;
 #define VS(T, NEc)                                                                                             \
     vocab_softmax_kernel<T, NEc><<<R, 256, 0, c.s>>>((const T*)G.logits(), p->Vp, probs, p->V, (T*)copy, p->Vp, \
                                                      p->V, 1.0f / p->temperature, p->greedy,                    \
-                                                     p->ids ? p->ids + (int64_t)step * B + G.r0 : nullptr)
+                                                     p->ids ? p->ids + (int64_t)step * B + G.r0 : nullptr, keep_rows)
 #define VSW(T, NEc)                                                                                                   \
     vocab_softmax_kernel<T, NEc, 1024><<<R, 1024, 0, c.s>>>((const T*)G.logits(), p->Vp, probs, p->V, (T*)copy, p->Vp, \
                                                             p->V, 1.0f / p->temperature, p->greedy,                    \
-                                                            p->ids ? p->ids + (int64_t)step * B + G.r0 : nullptr)
+                                                            p->ids ? p->ids + (int64_t)step * B + G.r0 : nullptr, keep_rows)
     const bool wide = p->V > 4096 && p->V <= 16384 && R <= 2048;      // few vocabulary-wide rows: 1024 threads per row
     if (c.dt == MSSR_F32) {
         if (wide) { if (p->V <= 10240) VSW(float, 10); else VSW(float, 16); }
@@ -1252,7 +1259,7 @@ static int step_bwd(const Ctx& c, int step) {
                           0, 1.f)))
             return rc;
         DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
-                (int64_t)B * 3 * d, nullptr, 0, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
+                (int64_t)B * 3 * d, G.self_mask(), p->T, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
                 p->T, 1, step, (int64_t)B * p->heads * p->T, (int64_t)B * 3 * d, (int64_t)B * d,
                 dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
@@ -1274,10 +1281,14 @@ static int step_bwd(const Ctx& c, int step) {
     }
     char* de = G.rows(p->d_e, step, d);
     if (step > 0) {
-        float* dprev = p->dprobs + ((int64_t)(step - 1) * B + G.r0) * p->V;
-        // dprobs[step-1] += d_e . E^T      (W as [N=V, K=d] = E itself)
-        if ((rc = gemm_nt(c, de, d, p->emb, d, dprev, p->V, R, p->V, d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, 1.f,
-                          MSSR_F32, 0.f, 0)))
+        // dprobs[step-1] += d_e . E^T      (W as [N=V, K=d] = E itself); teacher-forced sentences took a preset input at
+        // this step, not their previous output
+        const int skip = step < p->forced_steps ? p->forced_rows - G.r0 : 0;
+        const int f0 = skip > 0 ? (skip < R ? skip : R) : 0;
+        float* dprev = p->dprobs + ((int64_t)(step - 1) * B + G.r0 + f0) * p->V;
+        if (R - f0 > 0 &&
+            (rc = gemm_nt(c, de + (int64_t)f0 * d * es, d, p->emb, d, dprev, p->V, R - f0, p->V, d, nullptr, 0, nullptr, 0,
+                          nullptr, 0, 1.f, 1.f, MSSR_F32, 0.f, 0)))
             return rc;
     }
     MSSR_LAUNCH_OK("decode_step_bwd");

@@ -244,7 +244,7 @@ def clear_pack_cache():
 class _Spec:
     """Everything about one decode call that is not a tensor autograd tracks."""
     __slots__ = ("pack", "B", "Ls", "T", "heads", "training", "p_drop", "p_attn", "temperature", "seed", "src_mask",
-                 "bos", "pe", "save", "eval_rows")
+                 "bos", "pe", "save", "eval_rows", "forced", "pad")
 
 
 def _bgemm_t(dy, x, seg=None):
@@ -338,6 +338,15 @@ def _make_plan(spec, mem, greedy=False):
         stats=e(3 * NL + 1, 2, Ts * B, dtype=torch.float32), nf=e(Ts * B, d), logits=e(B, Vp), tmp=e(B, d),
         ws=ops._workspace(dev))
     bufs["in_all"][0, :, spec.bos] = 1
+    forced = None if greedy else getattr(spec, "forced", None)
+    if forced is not None:          # teacher-forced sentences [0, F): one-hot target words as the inputs of steps < Tf
+        Tf, F = forced.shape
+        rows = bufs["in_all"][:Tf, :F]
+        rows[0].zero_()
+        rows.scatter_(2, forced.unsqueeze(-1), 1)
+        smask = torch.zeros(B, T, dtype=torch.uint8, device=dev)
+        smask[:F, :Tf] = forced.t().eq(spec.pad)
+        bufs["self_mask"] = smask
     plan = L.DecodePlan()
     plan.dtype = L.F32 if cd == torch.float32 else L.BF16
     plan.B, plan.d, plan.heads, plan.ff, plan.n_layers = B, d, spec.heads, ff, NL
@@ -358,6 +367,10 @@ def _make_plan(spec, mem, greedy=False):
     for name in ("mem_kv", "in_all", "probs", "X", "qkv", "actD", "actF", "stats", "nf", "logits", "tmp"):
         setattr(plan, name, bufs[name].data_ptr())
     plan.gemm_ws, plan.gemm_ws_bytes = bufs["ws"].data_ptr(), bufs["ws"].numel() * 4
+    if forced is not None:
+        plan.forced_rows, plan.forced_steps = forced.shape[1], forced.shape[0]
+        plan.self_mask = bufs["self_mask"].data_ptr()
+        plan.n_chunks = 1
     return plan, bufs
 
 
@@ -471,7 +484,12 @@ class _SoftDecode(Function):
         dlg = g["dlogits"][:, :V]
         gW_gen = _bgemm_t(dlg, bufs["nf"], seg)
         gb_gen = _colsum(dlg)
-        gE = _bgemm_t(bufs["in_all"][:T].view(R, Vp)[:, :V], g["d_e"], seg)
+        d_e = g["d_e"]
+        if getattr(spec, "forced", None) is not None:
+            # a forced <blank> input is an nn.Embedding lookup at padding_idx in the reference: no gradient to that row
+            Tf, F = spec.forced.shape
+            d_e.view(T, B, d)[:Tf, :F].masked_fill_(spec.forced.eq(spec.pad).unsqueeze(-1), 0)
+        gE = _bgemm_t(bufs["in_all"][:T].view(R, Vp)[:, :V], d_e, seg)
 
         out = [None, g_mem, gE, ln_g[3 * NL, 0], ln_g[3 * NL, 1], gW_gen, gb_gen]
         for l in range(NL):
@@ -509,9 +527,15 @@ def _make_spec(model, cfg, memory_bank, src_lengths, steps, params):
     return spec
 
 
-def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0):
+def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0, forced_ids=None):
     """vocab_probs [steps, B, V] (float) of the step-wise soft decode of ``model`` over
     ``memory_bank`` [Ls, B, d] (the bonded encoder states).
+
+    ``forced_ids`` Long [Tf, F]: sentences [0, F) are TEACHER-FORCED for the steps below Tf -- step s reads the word
+    forced_ids[s] instead of the previous step's distribution and <blank> target positions are masked as keys of the
+    self attention, i.e. probs[:Tf, :F] is softmax(generator(TransformerDecoder.forward(forced_ids, step=None)))
+    (the reconstruction pass, onmt/trainer_wgan_wh.py:632-664) computed in the sweep the soft decodes run anyway;
+    see mssr_decode_plan.forced_rows.  Their steps from Tf on are unspecified.
 
     ``eval_rows`` > 0: two decodes in one sweep -- sentences [0, eval_rows) are decoded in EVAL mode (no dropout) and
     carry no gradient (the critics' fake text, onmt/trainer_wgan_wh.py:530-535), the rest follow ``model.training``
@@ -521,6 +545,12 @@ def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0):
     spec.eval_rows = int(eval_rows)
     if not 0 <= spec.eval_rows < memory_bank.shape[1]:
         raise ValueError("eval_rows must leave at least one differentiable sentence")
+    spec.forced, spec.pad = None, int(cfg.pad_idx)
+    if forced_ids is not None:
+        if (forced_ids.dim() != 2 or forced_ids.dtype != torch.int64 or forced_ids.shape[0] > spec.T
+                or forced_ids.shape[1] > memory_bank.shape[1] or spec.eval_rows):
+            raise ValueError("forced_ids: Long [Tf <= steps, F <= B] expected, and no eval_rows")
+        spec.forced = forced_ids.contiguous()
     needs = torch.is_grad_enabled() and (memory_bank.requires_grad or any(p.requires_grad for p in params))
     spec.save = bool(needs)
     mem = memory_bank.transpose(0, 1).contiguous()          # [B, Ls, d]

@@ -205,7 +205,8 @@ class Trainer:
     def vocab_loss_from_probs(self, probs, target, batch_size):
         """The same loss on probabilities: NLL(log p) only reads p at the target ids, so the log is
         taken after the gather (T*B values) instead of over the whole [T*B, V] tensor."""
-        p = probs.reshape(-1, probs.size(-1)).gather(1, target.view(-1, 1)).squeeze(1)
+        # probs [T, B, V] is usually a slice of a sweep's output: gather in place, no contiguous copy of the slice
+        p = probs.gather(2, target.view(probs.size(0), probs.size(1), 1)).reshape(-1)
         nll = -p.log()
         if not self.cfg.sent_stop_aware:
             nll = nll * target.ne(self.cfg.pad_idx).to(nll.dtype)
@@ -536,15 +537,23 @@ class Trainer:
         rep_src, rep_tgt = rep_both[:, :B], rep_both[:, B:]
         src3, len3 = real_src.repeat(1, 3, 1), real_len.repeat(3)
         enc_state, mem, lengths = self._encode(src3, len3, torch.cat([real_rep.to(rep_both.dtype), rep_both], 1))
-        # teacher-forced self reconstruction on the first third
-        self.model.decoder.init_state(real_src, mem[:, :B], enc_state[:, :B])
-        dec_out, _ = self.model.decoder(batch.tgt, mem[:, :B], memory_lengths=lengths[:B])
-        lp = generator_probs(self.model, dec_out, cfg.dec_temperature, log=True)
-        l_noised = self.vocab_loss(lp.view(-1, lp.size(-1)), flat_target, B)
-        # both soft decodes at once
-        src2, len2 = src3[:, B:], len3[B:]
-        self.model.decoder.init_state(src2, mem[:, B:], enc_state[:, B:])
-        probs_all = soft_decode(self.model, cfg, mem[:, B:], len2, max_dec_steps)
+        if cfg.forced_rows_in_sweep and batch.tgt.size(0) <= max_dec_steps:
+            # the teacher-forced self reconstruction of the first third rides in the sweep of the two soft decodes
+            # (decode_engine.soft_decode, forced_ids): one pass over the decoder's weights instead of two
+            self.model.decoder.init_state(src3, None, None)
+            all3 = soft_decode(self.model, cfg, mem, len3, max_dec_steps, forced_ids=batch.tgt[:, :, 0])
+            l_noised = self.vocab_loss_from_probs(all3[:tgt_len, :B], flat_target, B)
+            probs_all = all3[:, B:]
+        else:
+            # teacher-forced self reconstruction on the first third
+            self.model.decoder.init_state(real_src, mem[:, :B], enc_state[:, :B])
+            dec_out, _ = self.model.decoder(batch.tgt, mem[:, :B], memory_lengths=lengths[:B])
+            lp = generator_probs(self.model, dec_out, cfg.dec_temperature, log=True)
+            l_noised = self.vocab_loss(lp.view(-1, lp.size(-1)), flat_target, B)
+            # both soft decodes at once
+            src2, len2 = src3[:, B:], len3[B:]
+            self.model.decoder.init_state(src2, mem[:, B:], enc_state[:, B:])
+            probs_all = soft_decode(self.model, cfg, mem[:, B:], len2, max_dec_steps)
         probs, cprobs = probs_all[:tgt_len, :B], probs_all[:, B:]
         l_rec = self.vocab_loss_from_probs(probs, flat_target, B)
         total = cfg.sr_loss_ratio * l_noised + cfg.sr_loss_ratio * l_rec

@@ -278,3 +278,58 @@ torch.save(out, sys.argv[1])
         worst = max(worst, err / max(scale, 1e-12))
         assert err <= 1e-2 * scale + floor, (k, err, scale)
     print("fused vs split LN backward: worst relative-to-scale error %.2e" % worst)
+
+
+def test_teacher_forced_rows_in_the_sweep_fp32(ops):
+    """soft_decode(forced_ids=...): the first F sentences of the sweep are teacher-forced (mssr_decode_plan.forced_rows)
+    -- their probabilities and every gradient must equal the full-sequence decoder pass on the same target
+    (TransformerDecoder.forward with step = None + generator softmax, the reconstruction pass of
+    onmt/trainer_wgan_wh.py:632-664, with its target-padding self-attention mask and no gradient into the embedding
+    row of <blank>), while the remaining sentences decode softly exactly as a sweep without forced rows gives them."""
+    from mssrnet_style_transfer_amd import style_generator_builder as SB
+    from mssrnet_style_transfer_amd.decode_engine import soft_decode
+    from mssrnet_style_transfer_amd.train_and_translate import generator_probs
+    cfg = MSSRConfig.small()
+    torch.manual_seed(3)
+    model = SB.build_main_model(cfg).cuda()
+    model.train()                                           # dropout 0 in the small config
+    F, S, Ls, Tf, T = 3, 4, 6, 5, 8
+    B = F + S
+    lens = torch.tensor([6, 4, 2, 6, 5, 3, 6], device="cuda")
+    src = torch.randint(9, cfg.vocab_size, (Ls, B, 1), device="cuda")
+    mem = torch.randn(Ls, B, cfg.d_model, device="cuda")
+    tgt = torch.randint(9, cfg.vocab_size, (Tf, F), device="cuda")
+    tgt[0] = cfg.bos_idx
+    tgt[3:, 1] = cfg.pad_idx                                # <blank> target positions (keys masked, no table gradient)
+    tgt[4:, 2] = cfg.pad_idx
+    wf = torch.randn(Tf, F, cfg.vocab_size, device="cuda")
+    ws = torch.randn(T, S, cfg.vocab_size, device="cuda")
+
+    def grads(m):
+        out = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        out["mem"] = m.grad.clone()
+        return out
+
+    # one sweep: forced + soft sentences
+    model.zero_grad()
+    m1 = mem.clone().requires_grad_(True)
+    model.decoder.init_state(src, None, None)
+    both = soft_decode(model, cfg, m1, lens, T, forced_ids=tgt)
+    ((both[:Tf, :F] * wf).sum() + (both[:, F:] * ws).sum()).backward()
+    got_p, got_g = both.detach(), grads(m1)
+    # reference: the full-sequence decoder on the forced sentences + a sweep over the soft ones
+    model.zero_grad()
+    m2 = mem.clone().requires_grad_(True)
+    model.decoder.init_state(src[:, :F], m2[:, :F], None)
+    dec_out, _ = model.decoder(tgt.unsqueeze(-1), m2[:, :F], memory_lengths=lens[:F])
+    pf = generator_probs(model, dec_out, cfg.dec_temperature, log=False).view(Tf, F, -1)
+    model.decoder.init_state(src[:, F:], None, None)
+    ps = soft_decode(model, cfg, m2[:, F:], lens[F:], T)
+    ((pf * wf).sum() + (ps * ws).sum()).backward()
+    want_g = grads(m2)
+    assert_close(got_p[:Tf, :F], pf.detach(), 1e-4, "teacher-forced probabilities")
+    assert_close(got_p[:, F:], ps.detach(), 1e-4, "soft sentences beside them")
+    assert set(got_g) == set(want_g)
+    assert_grads(got_g, want_g, 3e-4, "forced + soft sweep")
+    with pytest.raises(ValueError):
+        soft_decode(model, cfg, m1, lens, T, eval_rows=2, forced_ids=tgt)
