@@ -75,6 +75,11 @@ class MSSRConfig:
     # batched behind the embedding layer and backpropagates the summed objective once (the reference: three forward /
     # backward passes per critic, onmt/trainer_wgan_wh.py:545-620); same losses and gradients up to summation order
     batch_critic_passes: bool = True
+    # not a reference flag: in Trainer.train_wgan_step the critics' eval-mode inputs ride through the style generator and
+    # the encoder as eval_rows of the generator phase's calls while the batched call has at most this many tokens
+    # (3 * B * source length: short batches leave the chip under-filled, the extra rows are free); beyond it they are
+    # encoded on their own, forward-only, as train_discriminator does
+    eval_rows_max_tokens: int = 16384
     # not a reference flag: train_reconstruct's teacher-forced decoder pass (onmt/trainer_wgan_wh.py:632-664) runs as
     # B more sentences of the sweep that decodes its two soft texts (mssr_decode_plan.forced_rows) instead of as a
     # full-sequence pass of its own; same losses and gradients up to summation order

@@ -408,12 +408,27 @@ class Trainer:
             self.model.decoder.init_state(src2, mem, enc_state)
             probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
             return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], None, None
-        rep_all = self._gen_style_represents(torch.cat([labels, desired, desired, labels]), real_src.repeat(1, 4, 1),
-                                             real_len.repeat(4), eval_rows=B)
-        rep_d = rep_all[:, :B].detach()
-        rep, rep2, rep3 = rep_all[:, B:2 * B], rep_all[:, 2 * B:3 * B], rep_all[:, 3 * B:]
         src3, len3 = real_src.repeat(1, 3, 1), real_len.repeat(3)
-        _, mem, _ = self._encode(src3, len3, torch.cat([rep_d, rep, rep3], 1), eval_rows=B)
+        if 3 * B * real_src.size(0) > cfg.eval_rows_max_tokens:
+            # long batches fill the chip with the training sentences alone: the eval-mode sentences would only add
+            # their rows to the encoders' backward.  Encode them on their own (forward-only plans), share the decode.
+            self.style_generator.eval()
+            self.model.eval()
+            with torch.no_grad():
+                rep_d = self._gen_style_represents(labels, real_src, real_len)
+                _, mem_d, _ = self._encode(real_src, real_len, rep_d)
+            self.style_generator.train()
+            self.model.train()
+            rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1), len3)
+            rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
+            _, mem, _ = self._encode(src3[:, B:], len3[B:], torch.cat([rep, rep3], 1))
+            mem = torch.cat([mem_d.to(mem.dtype), mem], 1)
+        else:
+            rep_all = self._gen_style_represents(torch.cat([labels, desired, desired, labels]), real_src.repeat(1, 4, 1),
+                                                 real_len.repeat(4), eval_rows=B)
+            rep_d = rep_all[:, :B].detach()
+            rep, rep2, rep3 = rep_all[:, B:2 * B], rep_all[:, 2 * B:3 * B], rep_all[:, 3 * B:]
+            _, mem, _ = self._encode(src3, len3, torch.cat([rep_d, rep, rep3], 1), eval_rows=B)
         self.model.decoder.init_state(src3, None, None)
         both = soft_decode(self.model, cfg, mem, len3, max_dec_steps, eval_rows=B)     # no gradient into mem[:, :B]
         fake, probs_all = both[:tgt_len, :B].detach(), both[:, B:]
