@@ -8,23 +8,25 @@
 // (~40 VALU instructions per element, all on one CU), and the bytes a block pulls grow with its tile width while
 // one CU's load bandwidth does not.  Measured per launch (bs160, d = 512, dropout 0.1), against 5.4 + 4.4 us for the
 // two separate kernels plus ~1.3 us of kernel boundary: 16x16 tiles 11.8 us, 16x32 9.3, 16x64 9.8, 16x128 12.5.
-// The 16x32 tile is kept: ~1 % of the WGAN step.  All loads (dy, x, dres, gamma, W) are issued before the first use.
+// The 16x32 tile is kept for n = 512 (~1 % of the WGAN step); outputs of 1024 columns and more take 16x64 tiles (half
+// as many repeats of the row work).  All loads (dy, x, dres, gamma, W) are issued before the first use.
 // Waves per block (same tile, K split over the waves): 4 -> 8.9 ms per WGAN step in this kernel, 8 -> 8.3 (two waves
 // per SIMD overlap their load -> reduce -> MFMA chains), 16 -> 9.3; 8 waves with 16x64 tiles 8.4.
 #include "gemm_common.hpp"
 #include <initializer_list>
+#include <stdlib.h>
 
 namespace mssr {
 
 typedef unsigned lnb_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LNB_NW = 8;                  // waves per block (two per SIMD: one wave's load / reduce chain hides the other's)
 constexpr int LNB_THREADS = 64 * LNB_NW;
-constexpr int LNB_FN = 2;                  // 16-column fragments per block tile (see the measurements above)
-constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
+// 16-column fragments per block tile: template parameter LNB_FN (2, or 4 for wide outputs; see the measurements above)
 constexpr int LNB_G = 2;                   // k-steps per wave (K <= LNB_NW * LNB_G * 32 = 512)
 
-template <typename TO>
+template <typename TO, int LNB_FN>
 __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p) {
+    constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
     __shared__ __attribute__((aligned(16))) float red[LNB_NW][16][LNB_TSN];
     __shared__ float stat[LNB_NW][16][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -178,9 +180,20 @@ bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s) {
                           (const void*)a.lnb_gamma})
         if (q && !aligned(q, 16)) return false;
     if (a.lnb_p < 0.f || a.lnb_p >= 1.f) return false;
-    const dim3 grid((unsigned)((a.n + LNB_TSN - 1) / LNB_TSN), (unsigned)((a.m + 15) / 16), 1);
-    if (out_dtype == MSSR_BF16) klaunch(gemm_lnb_kernel<bf16>, grid, dim3(LNB_THREADS), 0, s, a);
-    else klaunch(gemm_lnb_kernel<float>, grid, dim3(LNB_THREADS), 0, s, a);
+    static const int64_t wide_n = [] {
+        const char* e = getenv("MSSR_LNB_WIDE_N");
+        return e ? (int64_t)atoll(e) : (int64_t)1024;      // WGAN step 54.56 ms with 16x32 everywhere, 54.07 with 16x64
+                                                            // from n = 1024 (the FFN inner gradient), 54.69 from n = 512
+    }();
+    if (a.n >= wide_n) {
+        const dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 15) / 16), 1);
+        if (out_dtype == MSSR_BF16) klaunch(gemm_lnb_kernel<bf16, 4>, grid, dim3(LNB_THREADS), 0, s, a);
+        else klaunch(gemm_lnb_kernel<float, 4>, grid, dim3(LNB_THREADS), 0, s, a);
+        return true;
+    }
+    const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 15) / 16), 1);
+    if (out_dtype == MSSR_BF16) klaunch(gemm_lnb_kernel<bf16, 2>, grid, dim3(LNB_THREADS), 0, s, a);
+    else klaunch(gemm_lnb_kernel<float, 2>, grid, dim3(LNB_THREADS), 0, s, a);
     return true;
 }
 
