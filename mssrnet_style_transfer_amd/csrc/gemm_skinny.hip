@@ -208,7 +208,9 @@ int gemm_skinny_tile(int64_t m, int64_t n, int64_t k) {
     }();
     static const int64_t f1_max_blocks = [] {
         const char* e = getenv("MSSR_SKINNY_F1_MAXBLOCKS");
-        return e ? (int64_t)atoll(e) : (int64_t)1500;
+        return e ? (int64_t)atoll(e) : (int64_t)900;     // WGAN step, 240-row sweep: 54.06 ms at 1500 (every decode product
+                                                          // on 16x16 tiles), 53.93 at 1400 (N = 1536 on 32x32), 53.86 at 900
+                                                          // (N = 1024 too) and at 600
     }();
     if (m <= 16) return 16;
     // vocabulary-sized products (generator, soft embedding): thousands of 16x16 blocks re-read the operands
