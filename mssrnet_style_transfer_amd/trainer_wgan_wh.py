@@ -668,14 +668,24 @@ class Trainer:
         return PhaseLog(("INIT_SL", "INIT_VL"), (l_style, l_v), check=self._label_check())
 
 
-def teacher_step_loss(classifier, batch, cfg):
-    """onmt/trainer_teacher.py:238-252: three forwards (ids / ids+</s> / full padded length), NLL summed."""
+def teacher_step_loss(classifier, batch, cfg, batched=True):
+    """onmt/trainer_teacher.py:238-252: three forwards (ids / ids+</s> / full padded length), NLL summed.
+    ``batched``: the three forwards are one call on 3B sentences (same weights; the shorter input is padded with
+    <blank> rows, which every length mask of the classifier ignores) -- the same loss and gradients up to summation
+    order, a third of the launches of a step that is launch-bound at bs16.  False: the reference's three calls."""
     src, src_lengths = batch.src, batch.src_lengths
     real_src, real_len = src[1:], src_lengths - 1
     labels = torch.tensor([cfg.label_token_ids.index(t) for t in src[0, :, 0].tolist()], device=src.device)
     pad_row = torch.full((1, batch.tgt.size(1), 1), cfg.pad_idx, dtype=torch.long, device=src.device)
     new_x = torch.cat([batch.tgt[1:], pad_row])
     nll = lambda lg: F.nll_loss(F.log_softmax(lg, -1), labels)  # noqa: E731
+    if batched:
+        B, Lmax = labels.numel(), max(real_src.size(0), new_x.size(0))
+        grow = lambda x: x if x.size(0) == Lmax else torch.cat([x, pad_row.expand(Lmax - x.size(0), -1, -1)])  # noqa: E731
+        x3 = torch.cat([grow(real_src), grow(new_x), grow(new_x)], 1)
+        len3 = torch.cat([real_len, real_len + 1, torch.ones_like(src_lengths) * new_x.size(0)])
+        lg3 = classifier(x3, len3)
+        return nll(lg3[:B]) + nll(lg3[B:2 * B]) + nll(lg3[2 * B:]), lg3[:B]
     logits = classifier(real_src, real_len)
     loss = nll(logits) + nll(classifier(new_x, real_len + 1))
     loss = loss + nll(classifier(new_x, torch.ones_like(src_lengths) * new_x.size(0)))

@@ -220,11 +220,13 @@ def test_soft_decode_and_teacher_step(ops, golden_phases):
     teacher.train()
     for p in teacher.parameters():
         p.requires_grad_(True)
-    loss, lg = teacher_step_loss(teacher, batch, cfg)
-    assert_close(loss, t["loss"], TOL)
-    assert_close(lg, t["logits"], TOL)
-    loss.backward()
-    assert_grads(grads_of(teacher), t["g"], 2e-4, "teacher")
+    for batched in (True, False):       # one call on 3B sentences / the reference's three calls
+        teacher.zero_grad()
+        loss, lg = teacher_step_loss(teacher, batch, cfg, batched=batched)
+        assert_close(loss, t["loss"], TOL)
+        assert_close(lg, t["logits"], TOL)
+        loss.backward()
+        assert_grads(grads_of(teacher), t["g"], 2e-4, "teacher (batched=%s)" % batched)
 
 
 def test_greedy_translate_matches_reference_tokens(ops, golden_phases, golden_greedy):
