@@ -244,7 +244,7 @@ def clear_pack_cache():
 class _Spec:
     """Everything about one decode call that is not a tensor autograd tracks."""
     __slots__ = ("pack", "B", "Ls", "T", "heads", "training", "p_drop", "p_attn", "temperature", "seed", "src_mask",
-                 "bos", "pe", "save", "eval_rows", "forced", "pad")
+                 "bos", "pe", "save", "eval_rows", "forced", "pad", "groups")
 
 
 def _bgemm_t(dy, x, seg=None):
@@ -385,27 +385,54 @@ class _SoftDecode(Function):
             ctx.spec, ctx.plan, ctx.bufs = spec, plan, bufs
             ctx.pin = spec.pack.jobs.pin()      # the backward reads the pack: no in-place refresh until then
             ctx.mem_meta = (mem.shape, mem.dtype)
-            ctx.save_for_backward(probs)        # read by the softmax backward of every step
-        return probs
+        groups = getattr(spec, "groups", None)
+        if groups is None:
+            if spec.save:
+                ctx.save_for_backward(probs)    # read by the softmax backward of every step
+            return probs
+        if spec.save:
+            ctx.probs = probs                   # not an output itself (the outputs are views of it): no reference cycle
+        # the caller's row groups as separate outputs (views of the slab): their gradients arrive one by one and the
+        # backward lays them into its slab itself, instead of autograd padding every slice of one big output with
+        # zeros to the full [T, B, V] and adding the padded copies up (~2 GB of traffic per WGAN step)
+        return tuple(probs[:te, b0:b1] for te, b0, b1 in groups)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, dprobs):
+    def backward(ctx, *douts):
         spec, plan, bufs = ctx.spec, ctx.plan, ctx.bufs
         if bufs is None:
             raise RuntimeError("soft decode: backward called twice (activations were released)")
-        probs, = ctx.saved_tensors
+        probs = ctx.saved_tensors[0] if getattr(spec, "groups", None) is None else ctx.probs
         assert probs.data_ptr() == plan.probs
         pk = spec.pack
         lib = L.load()
-        cd, dev = pk.cd, dprobs.device
+        cd, dev = pk.cd, probs.device
         B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
         H = spec.heads
         R = T * B
         z = lambda *shape, dtype=cd: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
         E0 = spec.eval_rows         # sentences [0, E0) ran in eval mode and carry no gradient: the sweep skips them
-        g = dict(dprobs=dprobs.to(torch.float32).clone(memory_format=torch.contiguous_format),
+        # the sweep accumulates into dprobs in place (step s adds the input gradient of step s+1): a slab of its own
+        groups = getattr(spec, "groups", None)
+        dprobs = e(T, B, V, dtype=torch.float32)
+        if groups is None:
+            dprobs[:, E0:].copy_(douts[0][:, E0:])
+        else:
+            dprobs[:, E0:].zero_()
+            seen = []
+            for (te, b0, b1), dg in zip(groups, douts):
+                if dg is None or b1 <= E0:
+                    continue
+                b0 = max(b0, E0)
+                dg = dg[:, dg.shape[1] - (b1 - b0):]
+                if any(not (b1 <= c0 or c1 <= b0) for _, c0, c1 in seen):
+                    dprobs[:te, b0:b1].add_(dg)
+                else:
+                    dprobs[:te, b0:b1].copy_(dg)
+                seen.append((te, b0, b1))
+        g = dict(dprobs=dprobs,
                  dlogits=z(R, Vp), dX=e(2, B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
                  dctx=e(NL, 2, R, d), ds_self=e(NL, 2, T, B * H, T, dtype=torch.float32),
                  ds_ctx=e(NL, 2, T, B * H, Ls, dtype=torch.float32),
@@ -499,7 +526,7 @@ class _SoftDecode(Function):
                     gW_1[l], gb_1[l], gW_2[l], gb_2[l],
                     ln_g[3 * l, 0], ln_g[3 * l, 1], ln_g[3 * l + 1, 0], ln_g[3 * l + 1, 1], ln_g[3 * l + 2, 0],
                     ln_g[3 * l + 2, 1]]
-        ctx.bufs = ctx.plan = ctx.pin = None
+        ctx.bufs = ctx.plan = ctx.pin = ctx.probs = None
         return tuple(out)
 
 
@@ -527,7 +554,7 @@ def _make_spec(model, cfg, memory_bank, src_lengths, steps, params):
     return spec
 
 
-def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0, forced_ids=None):
+def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0, forced_ids=None, groups=None):
     """vocab_probs [steps, B, V] (float) of the step-wise soft decode of ``model`` over
     ``memory_bank`` [Ls, B, d] (the bonded encoder states).
 
@@ -536,6 +563,10 @@ def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0, forced
     self attention, i.e. probs[:Tf, :F] is softmax(generator(TransformerDecoder.forward(forced_ids, step=None)))
     (the reconstruction pass, onmt/trainer_wgan_wh.py:632-664) computed in the sweep the soft decodes run anyway;
     see mssr_decode_plan.forced_rows.  Their steps from Tf on are unspecified.
+
+    ``groups`` = [(t_end, b0, b1), ...]: return the tuple of probs[:t_end, b0:b1] (views of one slab) instead of the
+    whole tensor -- what a caller that batched several decodes into the sweep reads; each group gets its gradient
+    directly (no zero-padded full-size gradient per slice).
 
     ``eval_rows`` > 0: two decodes in one sweep -- sentences [0, eval_rows) are decoded in EVAL mode (no dropout) and
     carry no gradient (the critics' fake text, onmt/trainer_wgan_wh.py:530-535), the rest follow ``model.training``
@@ -551,6 +582,13 @@ def soft_decode(model, cfg, memory_bank, src_lengths, steps, eval_rows=0, forced
                 or forced_ids.shape[1] > memory_bank.shape[1] or spec.eval_rows):
             raise ValueError("forced_ids: Long [Tf <= steps, F <= B] expected, and no eval_rows")
         spec.forced = forced_ids.contiguous()
+    spec.groups = None
+    if groups is not None:
+        spec.groups = [(int(te), int(b0), int(b1)) for te, b0, b1 in groups]
+        for te, b0, b1 in spec.groups:
+            if not (0 < te <= spec.T and 0 <= b0 < b1 <= memory_bank.shape[1]):
+                raise ValueError("soft_decode: group (%d, %d, %d) outside [steps=%d, B=%d]" % (te, b0, b1, spec.T,
+                                                                                             memory_bank.shape[1]))
     needs = torch.is_grad_enabled() and (memory_bank.requires_grad or any(p.requires_grad for p in params))
     spec.save = bool(needs)
     mem = memory_bank.transpose(0, 1).contiguous()          # [B, Ls, d]

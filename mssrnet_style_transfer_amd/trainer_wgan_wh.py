@@ -430,9 +430,10 @@ class Trainer:
             rep, rep2, rep3 = rep_all[:, B:2 * B], rep_all[:, 2 * B:3 * B], rep_all[:, 3 * B:]
             _, mem, _ = self._encode(src3, len3, torch.cat([rep_d, rep, rep3], 1), eval_rows=B)
         self.model.decoder.init_state(src3, None, None)
-        both = soft_decode(self.model, cfg, mem, len3, max_dec_steps, eval_rows=B)     # no gradient into mem[:, :B]
-        fake, probs_all = both[:tgt_len, :B].detach(), both[:, B:]
-        return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], fake, rep_d
+        fake, probs, sprobs = soft_decode(self.model, cfg, mem, len3, max_dec_steps, eval_rows=B,    # no gradient into
+                                          groups=[(tgt_len, 0, B), (max_dec_steps, B, 2 * B),     # mem[:, :B]
+                                                  (tgt_len, 2 * B, 3 * B)])
+        return rep2, probs, sprobs, fake.detach(), rep_d
 
     def _train_generator_batched(self, batch, _shared=None):
         """train_generator with its independent pieces batched (cfg.batch_generator_phase): the reference
@@ -556,9 +557,9 @@ class Trainer:
             # the teacher-forced self reconstruction of the first third rides in the sweep of the two soft decodes
             # (decode_engine.soft_decode, forced_ids): one pass over the decoder's weights instead of two
             self.model.decoder.init_state(src3, None, None)
-            all3 = soft_decode(self.model, cfg, mem, len3, max_dec_steps, forced_ids=batch.tgt[:, :, 0])
-            l_noised = self.vocab_loss_from_probs(all3[:tgt_len, :B], flat_target, B)
-            probs_all = all3[:, B:]
+            forced, probs, cprobs = soft_decode(self.model, cfg, mem, len3, max_dec_steps, forced_ids=batch.tgt[:, :, 0],
+                                                groups=[(tgt_len, 0, B), (tgt_len, B, 2 * B), (max_dec_steps, 2 * B, 3 * B)])
+            l_noised = self.vocab_loss_from_probs(forced, flat_target, B)
         else:
             # teacher-forced self reconstruction on the first third
             self.model.decoder.init_state(real_src, mem[:, :B], enc_state[:, :B])
@@ -569,7 +570,7 @@ class Trainer:
             src2, len2 = src3[:, B:], len3[B:]
             self.model.decoder.init_state(src2, mem[:, B:], enc_state[:, B:])
             probs_all = soft_decode(self.model, cfg, mem[:, B:], len2, max_dec_steps)
-        probs, cprobs = probs_all[:tgt_len, :B], probs_all[:, B:]
+            probs, cprobs = probs_all[:tgt_len, :B], probs_all[:, B:]
         l_rec = self.vocab_loss_from_probs(probs, flat_target, B)
         total = cfg.sr_loss_ratio * l_noised + cfg.sr_loss_ratio * l_rec
         s_src = self.classifier.do_cls(rep_src.transpose(0, 1), real_len)

@@ -333,3 +333,38 @@ def test_teacher_forced_rows_in_the_sweep_fp32(ops):
     assert_grads(got_g, want_g, 3e-4, "forced + soft sweep")
     with pytest.raises(ValueError):
         soft_decode(model, cfg, m1, lens, T, eval_rows=2, forced_ids=tgt)
+
+
+def test_row_groups_as_separate_outputs_fp32(ops):
+    """soft_decode(groups=...): the caller's row groups come back as separate outputs whose gradients the backward lays
+    into its slab itself; values and every gradient must equal slicing the single-output form (incl. overlapping
+    groups, a group that is never used, and eval_rows)."""
+    from mssrnet_style_transfer_amd.decode_engine import soft_decode
+    cfg = MSSRConfig.small()
+    model, src, lens, mem = setup(cfg, 7, 6, seed=4)
+    model.train()
+    T, E = 6, 2
+    groups = [(4, 0, 2), (T, 2, 5), (3, 4, 7), (5, 5, 7)]
+    w = [torch.randn(te, b1 - b0, cfg.vocab_size, device="cuda") for te, b0, b1 in groups]
+
+    def grads(m):
+        out = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        out["mem"] = m.grad.clone()
+        return out
+
+    res = []
+    for use_groups in (True, False):
+        model.zero_grad()
+        m = mem.clone().requires_grad_(True)
+        model.decoder.init_state(src, None, None)
+        if use_groups:
+            outs = soft_decode(model, cfg, m, lens, T, eval_rows=E, groups=groups)
+        else:
+            full = soft_decode(model, cfg, m, lens, T, eval_rows=E)
+            outs = [full[:te, b0:b1] for te, b0, b1 in groups]
+        loss = sum((o * wi).sum() for o, wi, k in zip(outs, w, range(4)) if k != 0)     # group 0 (eval rows): unused
+        loss.backward()
+        res.append(([o.detach().clone() for o in outs], grads(m)))
+    for a, b in zip(res[0][0], res[1][0]):
+        assert torch.equal(a, b)
+    assert_grads(res[0][1], res[1][1], 1e-5, "row groups")
