@@ -499,6 +499,12 @@ typedef struct {
      * step-wise reference path has none).  Not with greedy or eval_rows. */
     int forced_rows, forced_steps;
     const uint8_t* self_mask;
+    /* Sentences that need fewer steps than the sweep has (a batched sweep serves decodes of different lengths): the
+     * BACKWARD steps >= late_step cover sentences [late_row0, B) only; the caller guarantees that the others carry
+     * no gradient at those steps (dprobs zero) and has ZEROED their rows of steps >= late_step in dqkv, dactD, dactF,
+     * dctx, d_e, dnf, ds_self and ds_ctx (the slabs the gathers and the parameter-gradient contractions read over all
+     * steps).  late_row0 = 0: every backward step covers [bwd_row0, B).  Needs n_chunks = 1. */
+    int late_step, late_row0;
 } mssr_decode_plan;
 /* One decode step: embeds in_all[step], runs the layers with the cache rows 0..step, writes
  * probs[step] and in_all[step+1]. */

@@ -944,6 +944,9 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
                  "%s: eval_rows / bwd_row0 outside the batch", who);
     MSSR_REQUIRE((p->eval_rows == 0 && p->bwd_row0 == 0) || (p->n_chunks == 1 && p->eval_rows <= p->bwd_row0),
                  "%s: a mixed eval / train sweep needs n_chunks = 1 and eval_rows <= bwd_row0", who);
+    MSSR_REQUIRE(p->late_row0 >= 0 && p->late_row0 < p->B && p->late_step >= 0 && p->late_step <= p->T &&
+                     (p->late_row0 == 0 || p->n_chunks == 1),
+                 "%s: late_row0 / late_step outside the batch / the steps (or with n_chunks > 1)", who);
     MSSR_REQUIRE(p->forced_rows >= 0 && p->forced_rows <= p->B && p->forced_steps >= 0 && p->forced_steps <= p->T,
                  "%s: forced_rows / forced_steps outside the batch / the steps", who);
     MSSR_REQUIRE(p->forced_rows == 0 || (!p->greedy && p->eval_rows == 0 && p->bwd_row0 == 0),
@@ -1355,11 +1358,21 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
         }
     }
     int rc = MSSR_OK;
+    // backward steps from late_step on cover sentences [late_row0, B) only (the others' gradients are zero there)
+    auto ctx_at = [&](int i, int step) -> Ctx {
+        Ctx c = cs[i];
+        if (backward && p->late_row0 > c.b0 && step >= p->late_step) {
+            c.Bc = c.b0 + c.Bc - p->late_row0;
+            c.b0 = p->late_row0;
+            c.hash_row_off = c.b0;
+        }
+        return c;
+    };
     auto run_chunk = [&](int i) -> int {
         int r = MSSR_OK;
         for (int k = 0; k < s_end - s_begin && r == MSSR_OK; ++k) {
             const int step = backward ? s_end - 1 - k : s_begin + k;
-            r = backward ? step_bwd(cs[i], step) : step_fwd(cs[i], step);
+            r = backward ? step_bwd(ctx_at(i, step), step) : step_fwd(cs[i], step);
         }
         return r;
     };
@@ -1372,7 +1385,8 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
     } else if (cap != hipStreamCaptureStatusNone || !use_threads) {
         for (int k = 0; k < s_end - s_begin && rc == MSSR_OK; ++k) {
             const int step = backward ? s_end - 1 - k : s_begin + k;
-            for (int i = 0; i < nch && rc == MSSR_OK; ++i) rc = backward ? step_bwd(cs[i], step) : step_fwd(cs[i], step);
+            for (int i = 0; i < nch && rc == MSSR_OK; ++i)
+                rc = backward ? step_bwd(ctx_at(i, step), step) : step_fwd(cs[i], step);
         }
     } else {
         // one host thread per chunk: a launch costs the host about as much as these kernels run, so a

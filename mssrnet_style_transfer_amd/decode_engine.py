@@ -439,6 +439,27 @@ class _SoftDecode(Function):
                  d_e=e(R, d), dnf=e(R, d))
         for name, t in g.items():
             setattr(plan, name, t.data_ptr())
+        # sentences whose groups end before the sweep does carry no gradient at the later steps: when they are a
+        # prefix of the differentiable rows, the late backward steps skip them (mssr_decode_plan.late_step / late_row0)
+        late_step, late_row0 = 0, 0
+        if groups is not None and plan.n_chunks == 1 and os.environ.get("MSSR_DECODE_LATE", "1") != "0":
+            need = [0] * B
+            for te, b0, b1 in groups:
+                for b in range(b0, b1):
+                    need[b] = max(need[b], te)
+            r = E0
+            while r < B - 1 and need[r] < T:
+                r += 1
+            if r > E0 and need[r] == T and all(n == T for n in need[r:]):
+                late_step, late_row0 = max(need[E0:r]), r
+        if late_row0 and late_step < T:
+            plan.late_step, plan.late_row0 = late_step, late_row0
+            for name in ("dqkv", "dactD", "dactF", "dctx", "d_e", "dnf"):
+                t = g[name]
+                t.view(-1, T, B, t.shape[-1])[:, late_step:, E0:late_row0].zero_()
+            for name in ("ds_self", "ds_ctx"):
+                t = g[name]
+                t.view(NL * 2, T, B, -1)[:, late_step:, E0:late_row0].zero_()
         if E0:
             # the slabs that are contracted over ALL (step, sentence) rows must hold zeros where the sweep writes nothing
             for name in ("dqkv", "dactD", "dactF", "d_e", "dnf"):

@@ -421,18 +421,20 @@ class Trainer:
             self.model.train()
             rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1), len3)
             rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
-            _, mem, _ = self._encode(src3[:, B:], len3[B:], torch.cat([rep, rep3], 1))
+            _, mem, _ = self._encode(src3[:, B:], len3[B:], torch.cat([rep3, rep], 1))
             mem = torch.cat([mem_d.to(mem.dtype), mem], 1)
         else:
             rep_all = self._gen_style_represents(torch.cat([labels, desired, desired, labels]), real_src.repeat(1, 4, 1),
                                                  real_len.repeat(4), eval_rows=B)
             rep_d = rep_all[:, :B].detach()
             rep, rep2, rep3 = rep_all[:, B:2 * B], rep_all[:, 2 * B:3 * B], rep_all[:, 3 * B:]
-            _, mem, _ = self._encode(src3, len3, torch.cat([rep_d, rep, rep3], 1), eval_rows=B)
+            _, mem, _ = self._encode(src3, len3, torch.cat([rep_d, rep3, rep], 1), eval_rows=B)
         self.model.decoder.init_state(src3, None, None)
-        fake, probs, sprobs = soft_decode(self.model, cfg, mem, len3, max_dec_steps, eval_rows=B,    # no gradient into
-                                          groups=[(tgt_len, 0, B), (max_dec_steps, B, 2 * B),     # mem[:, :B]
-                                                  (tgt_len, 2 * B, 3 * B)])
+        # sentence order: critics' fake text (eval, tgt_len steps) | self-style text (tgt_len steps) | adversarial text
+        # (all steps) -- the longest decode last, so that the late backward steps run on it alone
+        fake, sprobs, probs = soft_decode(self.model, cfg, mem, len3, max_dec_steps, eval_rows=B,    # no gradient into
+                                          groups=[(tgt_len, 0, B), (tgt_len, B, 2 * B),           # mem[:, :B]
+                                                  (max_dec_steps, 2 * B, 3 * B)])
         return rep2, probs, sprobs, fake.detach(), rep_d
 
     def _train_generator_batched(self, batch, _shared=None):

@@ -335,16 +335,19 @@ def test_teacher_forced_rows_in_the_sweep_fp32(ops):
         soft_decode(model, cfg, m1, lens, T, eval_rows=2, forced_ids=tgt)
 
 
-def test_row_groups_as_separate_outputs_fp32(ops):
+@pytest.mark.parametrize("case", ["overlap", "late", "late_dropout"])
+def test_row_groups_as_separate_outputs_fp32(ops, case):
     """soft_decode(groups=...): the caller's row groups come back as separate outputs whose gradients the backward lays
     into its slab itself; values and every gradient must equal slicing the single-output form (incl. overlapping
-    groups, a group that is never used, and eval_rows)."""
+    groups, a group that is never used, and eval_rows).  "late": the short decodes are a prefix of the differentiable
+    sentences, so the last backward steps run on the long ones alone (mssr_decode_plan.late_step / late_row0) -- also
+    with dropout on, where the skipped launches must not shift the replayed masks of the others."""
     from mssrnet_style_transfer_amd.decode_engine import soft_decode
-    cfg = MSSRConfig.small()
+    cfg = MSSRConfig.small() if case != "late_dropout" else MSSRConfig.small(dropout=0.2, attention_dropout=0.2)
     model, src, lens, mem = setup(cfg, 7, 6, seed=4)
     model.train()
     T, E = 6, 2
-    groups = [(4, 0, 2), (T, 2, 5), (3, 4, 7), (5, 5, 7)]
+    groups = [(4, 0, 2), (T, 2, 5), (3, 4, 7), (5, 5, 7)] if case == "overlap" else [(4, 0, 2), (3, 2, 4), (2, 3, 5), (T, 5, 7)]
     w = [torch.randn(te, b1 - b0, cfg.vocab_size, device="cuda") for te, b0, b1 in groups]
 
     def grads(m):
@@ -355,6 +358,7 @@ def test_row_groups_as_separate_outputs_fp32(ops):
     res = []
     for use_groups in (True, False):
         model.zero_grad()
+        ops._state["seed_counter"] = 99         # the same dropout masks in both forms
         m = mem.clone().requires_grad_(True)
         model.decoder.init_state(src, None, None)
         if use_groups:
