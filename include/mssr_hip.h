@@ -503,8 +503,11 @@ typedef struct {
      * BACKWARD steps >= late_step cover sentences [late_row0, B) only; the caller guarantees that the others carry
      * no gradient at those steps (dprobs zero) and has ZEROED their rows of steps >= late_step in dqkv, dactD, dactF,
      * dctx, d_e, dnf, ds_self and ds_ctx (the slabs the gathers and the parameter-gradient contractions read over all
-     * steps).  late_row0 = 0: every backward step covers [bwd_row0, B).  Needs n_chunks = 1. */
-    int late_step, late_row0;
+     * steps).  late_row0 = 0: every backward step covers [bwd_row0, B).  Needs n_chunks = 1.
+     * late_fwd = 1: the FORWARD steps >= late_step skip sentences [0, late_row0) as well (their decodes have ended:
+     * probs, activations and cache rows of those steps are not written; a saving caller zeroes those rows of X, qkv,
+     * actD, actF, stats and nf, which the parameter-gradient contractions read).  Set it the same for both sweeps. */
+    int late_step, late_row0, late_fwd;
 } mssr_decode_plan;
 /* One decode step: embeds in_all[step], runs the layers with the cache rows 0..step, writes
  * probs[step] and in_all[step+1]. */

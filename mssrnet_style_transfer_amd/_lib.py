@@ -73,7 +73,7 @@ class DecodePlan(Structure):
                 + [(n, c_void_p) for n in ("dprobs", "dlogits", "dX", "dqkv", "dactD", "dactF", "dctx",
                                            "ds_self", "ds_ctx", "d_e", "dnf", "ids")]
                 + [("greedy", c_int), ("eval_rows", c_int), ("bwd_row0", c_int), ("forced_rows", c_int),
-                   ("forced_steps", c_int), ("self_mask", c_void_p), ("late_step", c_int), ("late_row0", c_int)])
+                   ("forced_steps", c_int), ("self_mask", c_void_p), ("late_step", c_int), ("late_row0", c_int), ("late_fwd", c_int)])
 
 
 class DecStackPlan(Structure):

@@ -1121,7 +1121,7 @@ static int step_fwd(const Ctx& c, int step) {
     float* probs = p->probs + ((int64_t)step * B + G.r0) * p->V;
     void* copy = G.rows(p->in_all, step + 1, p->Vp);                        // in_all has T+1 slots
     // teacher-forced sentences: their next input was preset by the caller, the step's output must not replace it
-    const int keep_rows = step + 1 < p->forced_steps ? p->forced_rows : 0;
+    const int keep_rows = step + 1 < p->forced_steps && p->forced_rows > G.r0 ? p->forced_rows - G.r0 : 0;
     const int ne = (p->V + 255) / 256;
 #define VS(T, NEc)                                                                                             \
     vocab_softmax_kernel<T, NEc><<<R, 256, 0, c.s>>>((const T*)G.logits(), p->Vp, probs, p->V, (T*)copy, p->Vp, \
@@ -1358,13 +1358,16 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
         }
     }
     int rc = MSSR_OK;
-    // backward steps from late_step on cover sentences [late_row0, B) only (the others' gradients are zero there)
+    // steps from late_step on cover sentences [late_row0, B) only: backward (the others' gradients are zero there)
+    // and, with late_fwd, forward too (their decodes have ended).  Dropout decisions are indexed by the row inside the
+    // launch: a forward that ran on the suffix is replayed with offset 0.
     auto ctx_at = [&](int i, int step) -> Ctx {
         Ctx c = cs[i];
-        if (backward && p->late_row0 > c.b0 && step >= p->late_step) {
+        if (p->late_row0 > c.b0 && step >= p->late_step && (backward || p->late_fwd)) {
             c.Bc = c.b0 + c.Bc - p->late_row0;
             c.b0 = p->late_row0;
-            c.hash_row_off = c.b0;
+            c.hash_row_off = p->late_fwd ? 0 : c.b0;
+            c.eval_rows = c.eval_rows > c.b0 ? c.eval_rows - c.b0 : 0;
         }
         return c;
     };
@@ -1372,7 +1375,7 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
         int r = MSSR_OK;
         for (int k = 0; k < s_end - s_begin && r == MSSR_OK; ++k) {
             const int step = backward ? s_end - 1 - k : s_begin + k;
-            r = backward ? step_bwd(ctx_at(i, step), step) : step_fwd(cs[i], step);
+            r = backward ? step_bwd(ctx_at(i, step), step) : step_fwd(ctx_at(i, step), step);
         }
         return r;
     };
@@ -1386,7 +1389,7 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
         for (int k = 0; k < s_end - s_begin && rc == MSSR_OK; ++k) {
             const int step = backward ? s_end - 1 - k : s_begin + k;
             for (int i = 0; i < nch && rc == MSSR_OK; ++i)
-                rc = backward ? step_bwd(ctx_at(i, step), step) : step_fwd(cs[i], step);
+                rc = backward ? step_bwd(ctx_at(i, step), step) : step_fwd(ctx_at(i, step), step);
         }
     } else {
         // one host thread per chunk: a launch costs the host about as much as these kernels run, so a

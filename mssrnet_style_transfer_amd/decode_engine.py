@@ -374,11 +374,40 @@ def _make_plan(spec, mem, greedy=False):
     return plan, bufs
 
 
+def _late_regime(spec, n_chunks):
+    """(late_step, late_row0) of a sweep whose row groups end at different steps: the sentences [0, late_row0) need no
+    step >= late_step (their groups end there, or they are eval rows of such a group) and all the others run to the
+    end -- the late steps then cover the suffix only (mssr_decode_plan.late_step / late_row0); (0, 0): no such split."""
+    groups = getattr(spec, "groups", None)
+    if groups is None or n_chunks != 1 or os.environ.get("MSSR_DECODE_LATE", "1") == "0":
+        return 0, 0
+    B, T = spec.B, spec.T
+    need = [0] * B
+    for te, b0, b1 in groups:
+        for b in range(b0, b1):
+            need[b] = max(need[b], te)
+    r = 0
+    while r < B - 1 and need[r] < T:
+        r += 1
+    if r > 0 and need[r] == T and all(n == T for n in need[r:]):
+        return max(need[:r]), r
+    return 0, 0
+
+
 class _SoftDecode(Function):
     @staticmethod
     def forward(ctx, spec, mem, *params):
         lib = L.load()
         plan, bufs = _make_plan(spec, mem)
+        late_step, late_row0 = _late_regime(spec, plan.n_chunks)
+        if late_row0 and os.environ.get("MSSR_DECODE_LATE_FWD", "1") != "0":
+            plan.late_step, plan.late_row0, plan.late_fwd = late_step, late_row0, 1
+            if spec.save:       # rows the late forward steps skip: finite (zero) where the contractions read them
+                T, B = spec.T, spec.B
+                for name in ("X", "qkv", "actD", "actF", "nf"):
+                    t = bufs[name]
+                    t.view(-1, T, B, t.shape[-1])[:, late_step:, :late_row0].zero_()
+                bufs["stats"].view(-1, T, B)[:, late_step:, :late_row0].zero_()
         L.check(lib.mssr_decode_fwd(ctypes.byref(plan), L.stream()), "decode_fwd")
         probs = bufs.pop("probs")
         if spec.save:
@@ -441,18 +470,8 @@ class _SoftDecode(Function):
             setattr(plan, name, t.data_ptr())
         # sentences whose groups end before the sweep does carry no gradient at the later steps: when they are a
         # prefix of the differentiable rows, the late backward steps skip them (mssr_decode_plan.late_step / late_row0)
-        late_step, late_row0 = 0, 0
-        if groups is not None and plan.n_chunks == 1 and os.environ.get("MSSR_DECODE_LATE", "1") != "0":
-            need = [0] * B
-            for te, b0, b1 in groups:
-                for b in range(b0, b1):
-                    need[b] = max(need[b], te)
-            r = E0
-            while r < B - 1 and need[r] < T:
-                r += 1
-            if r > E0 and need[r] == T and all(n == T for n in need[r:]):
-                late_step, late_row0 = max(need[E0:r]), r
-        if late_row0 and late_step < T:
+        late_step, late_row0 = _late_regime(spec, plan.n_chunks)
+        if late_row0:
             plan.late_step, plan.late_row0 = late_step, late_row0
             for name in ("dqkv", "dactD", "dactF", "dctx", "d_e", "dnf"):
                 t = g[name]
