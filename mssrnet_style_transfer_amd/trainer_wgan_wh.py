@@ -404,10 +404,11 @@ class Trainer:
                                                  real_len.repeat(3))
             rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
             src2, len2 = real_src.repeat(1, 2, 1), real_len.repeat(2)
-            enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep, rep3], 1))
+            enc_state, mem, _ = self._encode(src2, len2, torch.cat([rep3, rep], 1))      # the shorter decode first
             self.model.decoder.init_state(src2, mem, enc_state)
-            probs_all = soft_decode(self.model, cfg, mem, len2, max_dec_steps)
-            return rep2, probs_all[:, :B], probs_all[:tgt_len, B:], None, None
+            sprobs, probs = soft_decode(self.model, cfg, mem, len2, max_dec_steps,
+                                        groups=[(tgt_len, 0, B), (max_dec_steps, B, 2 * B)])
+            return rep2, probs, sprobs, None, None
         src3, len3 = real_src.repeat(1, 3, 1), real_len.repeat(3)
         if 3 * B * real_src.size(0) > cfg.eval_rows_max_tokens:
             # long batches fill the chip with the training sentences alone: the eval-mode sentences would only add
