@@ -198,6 +198,78 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const GemmArgs 
     }
 }
 
+// ---- fp32 operands (exact f32 MFMA, v_mfma_f32_16x16x4_f32): the style critic's fp32 island inside bf16 runs
+// (cfg.style_critic_fp32) and the fp32 parity runs -- rows in the hundreds, K <= 1024.  Same mapping as above: one block
+// per 16 x 16 tile, the 4 waves split K in chunks of 16 (wave w owns chunks w, w+4, ...), every 16-byte load of a wave
+// issued before its first MFMA.  A lane holds row (lane & 15) and the k-quad 4 (lane >> 4) .. +3 of a chunk; MFMA j of a
+// chunk multiplies element j of every quad, so the four quads of a chunk are summed by the instruction's own k index.
+// (The general kernel's 32 x 32 LDS tiles with a serial K loop: 13-16 us for 240 x 512 x 512; this one ~5 us.)
+constexpr int SKF_MAX_CHUNKS = 16;      // 16-k chunks per wave held in registers (K <= 4 * 16 * 16 = 1024)
+
+template <int NCH>
+__global__ __launch_bounds__(SK_THREADS) void gemm_skinny_f32_kernel(const GemmArgs p) {
+    __shared__ float red[4][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t n0 = (int64_t)blockIdx.x * 16, m0 = (int64_t)blockIdx.y * 16;
+    const float* A = reinterpret_cast<const float*>(p.a);
+    const float* W = reinterpret_cast<const float*>(p.b);
+    const int64_t ar = m0 + (lane & 15), wn = n0 + (lane & 15);
+    const float* ap = A + (ar < p.m ? ar : p.m - 1) * p.a_rs + 4 * (lane >> 4);
+    const float* wp = W + (wn < p.n ? wn : p.n - 1) * p.b_cs + 4 * (lane >> 4);
+    const int chunks = (int)(p.k / 16);
+    // this thread's output element and its epilogue operands, requested before the main loads
+    const int64_t erow = m0 + (threadIdx.x >> 4), ecol = n0 + (threadIdx.x & 15);
+    const bool eok = erow < p.m && ecol < p.n;
+    float bias = 0.f;
+    if (eok && p.bias) bias = p.bias[ecol];
+    f32x4 fa[NCH], fb[NCH];
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        int c = wave + 4 * g;
+        c = c < chunks ? c : chunks - 1;                  // clamped: unconditional loads stay one batch in flight
+        fa[g] = *reinterpret_cast<const f32x4*>(ap + 16 * c);
+        fb[g] = *reinterpret_cast<const f32x4*>(wp + 16 * c);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < NCH; ++g) {
+        const bool live = wave + 4 * g < chunks;          // a clamped (repeated) chunk contributes nothing
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[g][j], live ? fb[g][j] : 0.f, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[wave][((lane >> 4) * 4 + r) * 16 + (lane & 15)] = acc[r];
+    __syncthreads();
+    if (!eok) return;
+    const int e = threadIdx.x;
+    const float v = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+    epilogue_store<float, float>(p, v, erow, ecol, bias, reinterpret_cast<float*>(p.c),
+                                 reinterpret_cast<const float*>(p.residual), reinterpret_cast<const float*>(p.gate), 0);
+}
+
+// true when the fp32 K-split kernel took the problem
+static bool skinny_f32_try(const GemmArgs& a, int out_dtype, int64_t batch, hipStream_t s) {
+    static const bool enabled = [] {
+        const char* e = getenv("MSSR_SKINNY_F32");
+        return !e || atoi(e) != 0;
+    }();
+    if (!enabled || out_dtype != MSSR_F32 || batch != 1 || a.ln_colsum || a.lnb_x) return false;
+    if (a.m < 1 || a.m > 1024 || a.n < 1 || a.k < 16 || a.k % 16 != 0 || a.k > 4 * SKF_MAX_CHUNKS * 16) return false;
+    if (a.a_cs != 1 || a.b_rs != 1 || a.a_rs % 4 != 0 || a.b_cs % 4 != 0 || !aligned(a.a, 16) || !aligned(a.b, 16)) return false;
+    const int64_t blocks = ((a.m + 15) / 16) * ((a.n + 15) / 16);
+    if (blocks > 4096 || (a.m + 15) / 16 > 65535) return false;      // large problems: the LDS-tiled kernel reuses operands
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    (void)prof_take(&e0, &e1);
+    const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16));
+    const int per_wave = (int)((a.k / 16 + 3) / 4);
+    if (per_wave <= 4) klaunch_events(gemm_skinny_f32_kernel<4>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    else if (per_wave <= 8) klaunch_events(gemm_skinny_f32_kernel<8>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    else klaunch_events(gemm_skinny_f32_kernel<16>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    return true;
+}
+
 // 16x16 tiles (more blocks, 32 KB of loads each) while the row count is small; 32x32 tiles halve the
 // L2 traffic once there are plenty of blocks anyway (measured: bs160 decode 104.8 ms/step with 16x16
 // vs 107.9 with 32x32; M = 1280 projections 11.6 us with 32x32 vs 14.2 with 16x16)
@@ -287,6 +359,7 @@ bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch) {
 }
 
 bool gemm_skinny_try(const GemmArgs& a0, int in_dtype, int out_dtype, int64_t batch, hipStream_t s) {
+    if (in_dtype == MSSR_F32) return skinny_f32_try(a0, out_dtype, batch, s);
     if (!gemm_skinny_eligible(a0, in_dtype, batch)) return false;
     GemmArgs a = a0;
     a.ksplit = gemm_skinny_ksplit(a.k);

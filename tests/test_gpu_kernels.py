@@ -976,3 +976,31 @@ def test_gain_pick_twice_differentiable(ops, sigmoid):
     bad = labels.clone()
     bad[3] = C
     assert bool(torch.isnan(ops.gain_pick(base[:, :C], bad, ratio, sigmoid)[3]))
+
+
+@pytest.mark.parametrize("M,N,K", [(240, 512, 512), (80, 512, 256), (37, 130, 48), (1, 4, 16), (1000, 64, 1024)])
+def test_gemm_skinny_f32_kernel(ops, M, N, K):
+    """fp32 K-split kernel (exact f32 MFMA; the style critic's fp32 island and the fp32 parity runs): plain product,
+    bias + ReLU, residual + gate + beta accumulation, against float64; and the profile must name the K-split kernel."""
+    torch.manual_seed(M + N + K)
+    a = torch.randn(M, K, device="cuda")
+    w = torch.randn(N, K, device="cuda") / math.sqrt(K)
+    bias = torch.randn(N, device="cuda")
+    res = torch.randn(M, N, device="cuda")
+    want = a.double() @ w.double().t()
+    ops.start_profile()
+    got = ops.gemm(a, w, True, torch.float32)
+    rec = ops.stop_profile()
+    assert rec and rec[0]["kernel"].startswith("gemm_skinny_kernel<f32"), rec
+    assert_close(got, want.float(), 2e-6, "f32 K-split plain", floor=1e-6)
+    got = ops.gemm(a, w, True, torch.float32, bias=bias, relu=True)
+    assert_close(got, torch.relu(want + bias.double()).float(), 2e-6, "f32 K-split bias relu", floor=1e-6)
+    out = torch.randn(M, N, device="cuda")
+    ref = torch.where(res.double() > 0, 0.5 * want + res.double(), torch.zeros((), device="cuda", dtype=torch.float64)) \
+        + out.double()
+    got = ops.gemm(a, w, True, torch.float32, residual=res, gate=res, alpha=0.5, out=out, beta=1.0)
+    assert_close(got, ref.float(), 2e-6, "f32 K-split residual gate beta", floor=1e-6)
+    # strided operands (row stride > K) keep the kernel; unaligned ones fall back to the general kernel
+    big = torch.randn(M, K + 8, device="cuda")
+    assert_close(ops.gemm(big[:, :K], w, True, torch.float32), (big[:, :K].double() @ w.double().t()).float(), 2e-6,
+                 "strided A", floor=1e-6)
