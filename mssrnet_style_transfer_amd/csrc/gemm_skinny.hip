@@ -273,6 +273,8 @@ static bool skinny_f32_try(const GemmArgs& a, int out_dtype, int64_t batch, hipS
 // 16x16 tiles (more blocks, 32 KB of loads each) while the row count is small; 32x32 tiles halve the
 // L2 traffic once there are plenty of blocks anyway (measured: bs160 decode 104.8 ms/step with 16x16
 // vs 107.9 with 32x32; M = 1280 projections 11.6 us with 32x32 vs 14.2 with 16x16)
+// (32x32 tiles for the long-K decode products, K >= 1024 or K = 1536 at N = 512, measured in the WGAN step: 52.6 / 51.4 ms
+// against 50.7 ms with 16x16 -- 128 blocks are too few even though they halve the L2 traffic.)
 int gemm_skinny_tile(int64_t m, int64_t n, int64_t k) {
     static const int64_t f1_max_m = [] {
         const char* e = getenv("MSSR_SKINNY_F1_MAXM");
