@@ -21,7 +21,7 @@ import torch.nn as nn
 from .. import ops
 from ..modules.multi_headed_attn import MultiHeadedAttention
 from ..modules.position_ffn import PositionwiseFeedForward
-from ..utils.misc import sequence_mask
+from ..utils.misc import padding_mask
 from ..decoder_stack import run_stack
 from .decoder import DecoderBase
 
@@ -153,7 +153,7 @@ class TransformerDecoder(DecoderBase):
         x = self.embeddings(tgt, step=step).transpose(0, 1).contiguous()          # [B,T,d]
         memory = memory_bank.transpose(0, 1).contiguous()                          # [B,Ls,d]
         # the source width comes from the ids given to init_state, as in the reference (:304)
-        src_pad = ~sequence_mask(memory_lengths, self.state["src"].shape[0]).unsqueeze(1)
+        src_pad = padding_mask(memory_lengths, self.state["src"].shape[0]).unsqueeze(1)
         # column 0 of a SOFT input is the probability of word 0: comparing it with the padding index
         # reproduces the reference (:294,306), i.e. effectively no target padding mask on that path
         tgt_pad = tgt[:, :, 0].t().detach().eq(self.embeddings.word_padding_idx).unsqueeze(1)

@@ -12,7 +12,7 @@ from .. import ops
 from ..encoder_engine import run_stack
 from ..modules.multi_headed_attn import MultiHeadedAttention
 from ..modules.position_ffn import PositionwiseFeedForward
-from ..utils.misc import sequence_mask
+from ..utils.misc import padding_mask
 from .encoder import EncoderBase
 
 
@@ -69,7 +69,7 @@ class TransformerEncoder(EncoderBase):
         """The encoder behind its embedding layer: emb [L, B, d] (``self.embeddings`` of ids or of soft words, possibly
         of several inputs concatenated along the batch) -> (emb, memory_bank, lengths).  No reference counterpart as a
         method: it is the body of onmt/encoders/transformer.py:118-129 after the embedding call."""
-        pad = ~sequence_mask(lengths, max_len=emb.size(0))                 # [B, L], True = padding
+        pad = padding_mask(lengths, emb.size(0))                 # [B, L], True = padding
         out = run_stack(self, emb.transpose(0, 1), pad, eval_rows)         # all layers + final LN: one C call
         if out is None and eval_rows:
             raise RuntimeError("TransformerEncoder: eval_rows needs the encoder engine (not available for this graph / shape)")

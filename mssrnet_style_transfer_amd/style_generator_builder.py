@@ -18,7 +18,7 @@ from .encoder_engine import run_stack
 from .encoders.transformer import TransformerEncoder
 from .modules.embeddings import Embeddings
 from .modules.util_class import Cast
-from .utils.misc import sequence_mask
+from .utils.misc import padding_mask
 
 
 class ContextReps2(nn.Module):
@@ -34,7 +34,7 @@ class ContextReps2(nn.Module):
         B, Lx, _ = x_states.shape
         h = ops.linear(x_states, self.w_fn[0].weight, self.w_fn[0].bias, relu=True)
         w = ops.linear(h, self.w_fn[2].weight, self.w_fn[2].bias)               # [B, L, 1]
-        mask = ~sequence_mask(src_lengths, max_len=Lx).unsqueeze(1)             # [B, 1, L]
+        mask = padding_mask(src_lengths, Lx).unsqueeze(1)             # [B, 1, L]
         ww = ops.softmax(w.view(B, 1, 1, Lx), mask, 1.0)                        # softmax over time
         return ops.matmul(ww.view(B, 1, Lx), x_states, tb=False).view(B, -1)    # sum_t ww * x
 
@@ -116,7 +116,7 @@ class StyleGenerator2(nn.Module):
         # the style token row is neither scaled by sqrt(d) nor position-encoded (quirk 10)
         cls_emb = self.style_cls(desired_style).to(emb.dtype)
         x = torch.cat((cls_emb.unsqueeze(0), emb), 0).transpose(0, 1)
-        pad = ~sequence_mask(src_lengths + 1, max_len=src.size(0) + 1)
+        pad = padding_mask(src_lengths + 1, src.size(0) + 1)
         out = run_stack(enc, x, pad, eval_rows)
         if out is None and eval_rows:
             raise RuntimeError("StyleGenerator2: eval_rows needs the encoder engine (not available for this graph / shape)")
