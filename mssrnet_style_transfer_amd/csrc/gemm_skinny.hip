@@ -84,7 +84,8 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     float sx[F], sxx[F];
 #pragma unroll
     for (int f = 0; f < F; ++f) sx[f] = sxx[f] = 0.f;
-    // wave w owns k-steps s_begin + w, + 4, + 8 ... ; SK_GROUP of them in flight at a time
+    // wave w owns k-steps s_begin + w, + 4, + 8 ... ; SK_GROUP of them in flight at a time  (contiguous quarters per
+    // wave, so that one wave requests both halves of a 128-byte line back to back: WGAN step 51.0-51.6 ms against 50.8)
     for (int64_t s0 = s_begin + wave; s0 < s_end; s0 += 4 * SK_GROUP) {
         bf16x8 fa[SK_GROUP][F], fb[SK_GROUP][F];
 #pragma unroll
