@@ -16,9 +16,13 @@ classes by registering entries in ``sys.modules``:
   stub parent packages are created as well, plus the caller classes that end up in checkpoints
   (``onmt.models.model.NMTModel``, ``onmt.style_generator.StyleGenerator2``,
   ``onmt.style_generator_builder.{StyleClassifier, ContextReps2, StyleDiscriminator, BondLayer}``,
-  ``onmt.modules.util_class.{Elementwise, Cast}``, ``onmt.utils.misc.sequence_mask``), so
-  ``torch.load(checkpoint, weights_only=False)`` of a reference-pickled module yields drop-in
-  objects.
+  ``onmt.modules.util_class.{Elementwise, Cast}``, ``onmt.utils.misc.sequence_mask``), so a
+  reference-pickled module unpickles into drop-in objects.
+
+``load_checkpoint(path)`` is the loader to use for such files: torch's restricted unpickler
+(``weights_only=True``) with an allow-list of exactly the drop-in classes under their ``onmt.*`` paths and
+the torch.nn containers they are made of.  Nothing from the file is executed (no arbitrary ``find_class``,
+no ``__reduce__`` callables outside the list), and it needs no ``install()``.
 
 Nothing here touches the GPU; the classes fail loudly at ``forward`` time if the HIP library is absent.
 """
@@ -161,6 +165,34 @@ def reference_class_path(cls):
         if here == _PKG + rel and cls.__name__ in attrs:
             return name
     return None
+
+
+def checkpoint_allow_list():
+    """``(class, "onmt.path.Name")`` pairs + the torch.nn classes a reference checkpoint of this path is made of:
+    the argument of ``torch.serialization.safe_globals`` for ``load_checkpoint``."""
+    import torch.nn as nn
+    allow = []
+    for name, rel in list(L1_PATHS.items()) + list(STANDALONE_PATHS.items()):
+        mod = _mine(rel)
+        for attr, obj in vars(mod).items():
+            if isinstance(obj, type) and issubclass(obj, nn.Module) and obj.__module__ == mod.__name__:
+                allow.append((obj, name + "." + attr))
+    for name, (rel, attrs) in STANDALONE_CALLERS.items():
+        for attr in attrs:
+            allow.append((getattr(_mine(rel), attr), name + "." + attr))
+    allow += [nn.Linear, nn.LayerNorm, nn.Dropout, nn.ModuleList, nn.Sequential, nn.Softmax, nn.LogSoftmax, nn.ReLU,
+              nn.Sigmoid, nn.Tanh, nn.Embedding, nn.Parameter, set]
+    return allow
+
+
+def load_checkpoint(f, map_location=None):
+    """Loads a whole-module checkpoint as the reference writes them (``torch.save({'main_model': module, ...})``,
+    onmt/trainer_wgan_wh.py:1093-1100; ``torch.save(self.model)``, onmt/trainer_teacher.py:282) into the drop-in
+    classes WITHOUT a code-executing unpickle: ``weights_only=True`` under ``checkpoint_allow_list()``.  A file that
+    names any other global is refused by torch with the offending path in the message."""
+    import torch
+    with torch.serialization.safe_globals(checkpoint_allow_list()):
+        return torch.load(f, map_location=map_location, weights_only=True)
 
 
 class reference_class_paths:

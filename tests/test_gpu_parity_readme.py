@@ -250,11 +250,7 @@ def test_reference_pickled_checkpoint_runs_on_the_kernels(ops):
     """f4 / SURVEY 8b: modules pickled by the REFERENCE's classes (tests/golden/ref_pickles.pt), loaded through
     onmt_alias into the drop-in classes, moved to the GPU and run: outputs equal what the reference computed."""
     from mssrnet_style_transfer_amd import onmt_alias
-    onmt_alias.install(standalone=True)
-    try:
-        ck = torch.load(os.path.join(GOLDEN, "ref_pickles.pt"), weights_only=False)
-    finally:
-        onmt_alias.uninstall()
+    ck = onmt_alias.load_checkpoint(os.path.join(GOLDEN, "ref_pickles.pt"))   # weights_only=True + allow-list
     io = ck["io"]
     src, lens, desired, tgt = io["src"].cuda(), io["lens"].cuda(), io["desired"].cuda(), io["tgt"].cuda()
     for k in ("main_model", "style_generator", "style_discriminator", "text_discriminator", "teacher"):

@@ -69,11 +69,11 @@ def test_checkpoint_with_reference_class_paths_round_trips(alias):
         assert path in blob, path
     assert b"mssrnet_style_transfer_amd" not in blob
     assert type(nets["model"]).__module__ == "mssrnet_style_transfer_amd.style_generator_builder"   # restored
-    onmt_alias.uninstall()
-    with pytest.raises(ModuleNotFoundError):
-        torch.load(io.BytesIO(blob), weights_only=False)
+    with pytest.raises(Exception, match="(?i)unsupported global|weights_only"):
+        torch.load(io.BytesIO(blob), weights_only=True)          # not without the allow-list
+    onmt_alias.uninstall()                                        # the allow-listed loader needs no aliases
+    back = onmt_alias.load_checkpoint(io.BytesIO(blob))
     onmt_alias.install(standalone=True)
-    back = torch.load(io.BytesIO(blob), weights_only=False)
     assert back["step"] == 3
     for key, name in (("main_model", "model"), ("style_generator", "style_generator")):
         assert type(back[key]) is type(nets[name])
@@ -88,7 +88,7 @@ def test_reference_pickled_modules_load_into_the_drop_in_classes(alias):
     from mssrnet_style_transfer_amd.decoders.transformer import TransformerDecoder
     from mssrnet_style_transfer_amd.encoders.transformer import TransformerEncoder
     from mssrnet_style_transfer_amd.modules.multi_headed_attn import MultiHeadedAttention
-    ck = torch.load(os.path.join(GOLDEN, "ref_pickles.pt"), weights_only=False)
+    ck = onmt_alias.load_checkpoint(os.path.join(GOLDEN, "ref_pickles.pt"))     # restricted unpickler, allow-list only
     cfg = MSSRConfig.small()
     mine = B.build_all(cfg, device="cpu", seed=0)
     pairs = {"main_model": "model", "style_generator": "style_generator", "style_discriminator": "style_discriminator",
@@ -103,6 +103,18 @@ def test_reference_pickled_modules_load_into_the_drop_in_classes(alias):
     assert isinstance(m.encoder, TransformerEncoder) and isinstance(m.decoder, TransformerDecoder)
     assert isinstance(m.decoder.transformer_layers[0].context_attn, MultiHeadedAttention)
     assert isinstance(ck["style_generator"].encoder, TransformerEncoder)
+
+
+def test_allow_listed_loader_refuses_foreign_globals():
+    """A checkpoint naming anything outside the allow-list (here: os.system through __reduce__) is refused
+    before anything runs."""
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    buf = io.BytesIO()
+    torch.save({"main_model": Evil()}, buf)
+    with pytest.raises(Exception, match="(?i)unsupported global|weights_only"):
+        onmt_alias.load_checkpoint(io.BytesIO(buf.getvalue()))
 
 
 def test_reference_callers_built_around_the_drop_in_modules():
