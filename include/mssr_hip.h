@@ -126,9 +126,13 @@ int mssr_gemm(const mssr_gemm_desc* desc, void* stream);
  * live in a file-scope device array of MSSR_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until
  * the process ends (looked up once per device with hipGetSymbolAddress; nothing is ever allocated or freed).
  * A split-K problem whose slabs ceil(k/1024) * m * n * 4 bytes exceed that size is rejected with MSSR_ERR_ARG and a
- * message (mssr_gemm with a workspace takes it); problems that need no slabs (k <= 2048, or the general kernel's
- * shapes) run as in mssr_gemm.  All calls on one GPU share that GPU's array: calls that overlap in time on one GPU
- * (different streams, different threads) race on it -- serialise them or use mssr_gemm with per-stream workspaces.
+ * message (mssr_gemm with a workspace takes it); the limit applies only where mssr_gemm's own dispatch order would
+ * pick the K-split kernel: problems that need no slabs (k <= 2048, the pipelined kernel's shapes from 2048 rows on,
+ * the general kernel's shapes) run as in mssr_gemm whatever their size.
+ * PRECONDITION (hard): at most ONE mssr_gemm_noalloc call may be in flight per GPU at any time.  All calls on one GPU
+ * share that GPU's array, so split-K calls that overlap in time (two streams, two threads, two captured graphs
+ * replayed concurrently) silently corrupt each other's slabs -- keep every noalloc call of a GPU, and every graph
+ * that captured one, on ONE stream, or use mssr_gemm with a workspace per stream.
  * Nothing in the array has to start at zero: every slab element is written before it is read. */
 #define MSSR_NOALLOC_SCRATCH_BYTES (16u << 20)
 int mssr_gemm_noalloc(const mssr_gemm_desc* desc, void* stream);

@@ -280,6 +280,15 @@ extern "C" int mssr_gemm_is_skinny(const mssr_gemm_desc* d) {
     return gemm_skinny_eligible(a, d->in_dtype, d->batch_outer * d->batch_inner) ? 1 : 0;
 }
 
+// measured (scratch/pipe_bench.py): from this many rows on the LDS-tiled DMA kernel beats the K-split one
+static int64_t pipe_first_min_m() {
+    static const int64_t v = [] {
+        const char* e = getenv("MSSR_PIPE_FIRST_MINM");
+        return e ? (int64_t)atoll(e) : (int64_t)2048;
+    }();
+    return v;
+}
+
 static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
     MSSR_REQUIRE(d, "%s: null descriptor", who);
     MSSR_REQUIRE(valid_dtype(d->in_dtype) && valid_dtype(d->out_dtype), "%s: bad dtype", who);
@@ -318,12 +327,7 @@ static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
         set_error("%s: a segmented k needs the weight-gradient form (bf16, A m-contiguous, B n-contiguous, plain epilogue)", who);
         return MSSR_ERR_UNSUPPORTED;
     }
-    // measured (scratch/pipe_bench.py): from this many rows on the LDS-tiled DMA kernel beats the K-split one
-    static const int64_t pipe_first_min_m = [] {
-        const char* e = getenv("MSSR_PIPE_FIRST_MINM");
-        return e ? (int64_t)atoll(e) : (int64_t)2048;
-    }();
-    if (!d->no_skinny && d->m >= pipe_first_min_m && gemm_pipe_try(a, d->in_dtype, d->out_dtype, batch, s)) {
+    if (!d->no_skinny && d->m >= pipe_first_min_m() && gemm_pipe_try(a, d->in_dtype, d->out_dtype, batch, s)) {
         prof_end(pi, s, 4, d->in_dtype, d->out_dtype, 128, batch, d->m, d->n, d->k);
         MSSR_LAUNCH_OK("gemm(pipe)");
     }
@@ -410,8 +414,12 @@ extern "C" int mssr_gemm_noalloc(const mssr_gemm_desc* d, void* stream) {
         GemmArgs probe;
         gemm_fill_args(&local, probe);
         probe.partial = reinterpret_cast<float*>(uintptr_t(256));
-        if (!d->no_skinny && !d->ln_colsum &&
-            gemm_skinny_eligible(probe, d->in_dtype, d->batch_outer * d->batch_inner)) {
+        // mssr_gemm's own order (gemm_run): the pipelined kernel comes first from pipe_first_min_m rows on and needs
+        // no scratch (gemm_wide never sees k > 2048); only a problem the K-split kernel would really get is held to
+        // the size of the static array
+        const int64_t batch = d->batch_outer * d->batch_inner;
+        const bool pipe_first = d->m >= pipe_first_min_m() && gemm_pipe_eligible(probe, d->in_dtype, d->out_dtype, batch);
+        if (!d->no_skinny && !d->ln_colsum && !pipe_first && gemm_skinny_eligible(probe, d->in_dtype, batch)) {
             const int64_t need = gemm_skinny_ksplit(d->k) * d->m * d->n * (int64_t)sizeof(float);
             MSSR_REQUIRE(need <= (int64_t)MSSR_NOALLOC_SCRATCH_BYTES,
                          "gemm_noalloc: split-K slabs of a %lld x %lld x %lld product need %lld bytes, beyond the "

@@ -70,6 +70,7 @@ bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch);
 bool gemm_tn_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
 // returns true when the pipelined 128x128 LDS-DMA kernel took the problem (gemm_pipe.hip: large M, bf16)
 bool gemm_pipe_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
+bool gemm_pipe_eligible(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch);     // same test, no launch
 // returns true when the all-rows x 48-columns kernel took the problem (gemm_wide.hip: vocabulary-wide N, few rows, K 256 / 512)
 bool gemm_wide_try(const GemmArgs& a, int in_dtype, int out_dtype, int64_t batch, hipStream_t s);
 // LayerNorm backward fused with the product behind it (a.lnb_* set): false when the shape is outside its reach

@@ -296,8 +296,8 @@ static void pipe_launch(const PipeArgs& P, bool a_km, bool b_km, dim3 grid, hipS
     else klaunch(gemm_pipe_kernel<TO, false, false>, grid, dim3(PP_THREADS), 0, s, P);
 }
 
-// true when the pipelined kernel took the problem
-bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, hipStream_t s) {
+// Eligibility + launch plan of the pipelined kernel; nothing is launched.  false: outside its reach.
+static bool pipe_plan(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, PipeArgs& P, bool& a_km, bool& b_km) {
     static const bool enabled = [] {
         const char* e = getenv("MSSR_GEMM_PIPE");
         return !e || atoi(e) != 0;
@@ -308,7 +308,7 @@ bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch
     }();
     if (!enabled || in_dtype != MSSR_BF16 || g.ln_colsum || g.lnb_x) return false;
     if (g.k < 64 || g.k % 32 != 0 || g.m < 128 || g.n < 64) return false;
-    const bool a_km = g.a_cs == 1, b_km = g.b_rs == 1;
+    a_km = g.a_cs == 1; b_km = g.b_rs == 1;
     if (!a_km && b_km) return false;                         // A^T with k-contiguous B: not a form this path produces
     const int64_t a_ld = a_km ? g.a_rs : g.a_cs, b_ld = b_km ? g.b_cs : g.b_rs;
     if (!a_km && g.a_rs != 1) return false;
@@ -322,7 +322,6 @@ bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch
     if (!a_km && (g.bias || g.residual || g.gate || g.relu || g.drop_p > 0.f)) return false;
     const int64_t tm = (g.m + PP_BM - 1) / PP_BM, tn = (g.n + PP_BN - 1) / PP_BN;
     if (tm * tn > (int64_t)1 << 24 || batch > 65535) return false;
-    PipeArgs P;
     P.g = g;
     P.a_ld = a_ld; P.b_ld = b_ld;
     P.tiles_m = (int)tm; P.tiles_n = (int)tn;
@@ -364,12 +363,27 @@ bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch
             if (forced_ks > 0 && kmax >= 1) P.ksplit = (int)(forced_ks < kmax ? forced_ks : kmax);
         }
         if (tiles * P.ksplit < 16) return false;
-        if (P.ksplit > 1 && g.beta == 0.f &&
-            hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)(g.m * g.n * batch), s) != hipSuccess) return false;
     } else if (tiles < min_tiles) {
         return false;
     }
-    const dim3 grid((unsigned)(tm * tn), (unsigned)P.ksplit, (unsigned)batch);
+    return true;
+}
+
+// true when mssr_gemm's pipe-first rule would hand this problem to the pipelined kernel (no launch)
+bool gemm_pipe_eligible(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch) {
+    PipeArgs P;
+    bool a_km, b_km;
+    return pipe_plan(g, in_dtype, out_dtype, batch, P, a_km, b_km);
+}
+
+// true when the pipelined kernel took the problem
+bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch, hipStream_t s) {
+    PipeArgs P;
+    bool a_km, b_km;
+    if (!pipe_plan(g, in_dtype, out_dtype, batch, P, a_km, b_km)) return false;
+    if (!a_km && P.ksplit > 1 && g.beta == 0.f &&
+        hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)(g.m * g.n * batch), s) != hipSuccess) return false;
+    const dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)P.ksplit, (unsigned)batch);
     if (out_dtype == MSSR_F32) pipe_launch<float>(P, a_km, b_km, grid, s);
     else pipe_launch<bf16>(P, a_km, b_km, grid, s);
     return true;

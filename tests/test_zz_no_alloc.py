@@ -78,10 +78,23 @@ def test_noalloc_gemm_without_slabs_and_limits():
     L.check(lib.mssr_gemm(ctypes.byref(desc(a, w, c1)), L.stream()), "gemm")
     L.check(lib.mssr_gemm_noalloc(ctypes.byref(desc(a, w, c2)), L.stream()), "gemm_noalloc")
     assert torch.equal(c1, c2)
-    # beyond the static array: rejected with a message, nothing launched
-    a = torch.zeros(4096, 9632, device="cuda", dtype=torch.bfloat16)
+    # many rows, long K: mssr_gemm gives this to the LDS-DMA kernel (no scratch at all), so the static array's size
+    # is no limit for it -- same dispatch, same bits
+    a = torch.randn(4096, 9632, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(512, 9632, device="cuda", generator=g) / 98.0).bfloat16()
+    c1 = torch.empty(4096, 512, device="cuda", dtype=torch.bfloat16)
+    c2 = torch.full((4096, 512), float("nan"), device="cuda", dtype=torch.bfloat16)
+    assert lib.mssr_gemm_is_skinny(ctypes.byref(desc(a, w, c1))) == 0
+    L.check(lib.mssr_gemm(ctypes.byref(desc(a, w, c1)), L.stream()), "gemm")
+    L.check(lib.mssr_gemm_noalloc(ctypes.byref(desc(a, w, c2)), L.stream()), "gemm_noalloc")
+    assert torch.equal(c1, c2)
+    # a product the K-split kernel WOULD take, whose 10 slabs (20 MB) are beyond the static array: rejected with a
+    # message, nothing launched
+    a = torch.zeros(1024, 9632, device="cuda", dtype=torch.bfloat16)
     w = torch.zeros(512, 9632, device="cuda", dtype=torch.bfloat16)
-    c = torch.full((4096, 512), 7.0, device="cuda", dtype=torch.bfloat16)
+    c = torch.full((1024, 512), 7.0, device="cuda", dtype=torch.bfloat16)
+    ws = torch.empty(32 << 20, dtype=torch.uint8, device="cuda")
+    assert lib.mssr_gemm_is_skinny(ctypes.byref(desc(a, w, c, workspace=ws))) == 1
     rc = lib.mssr_gemm_noalloc(ctypes.byref(desc(a, w, c)), L.stream())
     assert rc == 1 and b"static scratch" in lib.mssr_last_error()
     torch.cuda.synchronize()
