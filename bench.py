@@ -43,7 +43,64 @@ def parse():
     ap.add_argument("--max-words", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dry-run-gloo", action="store_true",
+                    help="launcher rehearsal on CPU: start the ranks, join a gloo group, all-reduce a rank census, "
+                         "print it and exit (no GPU, no model)")
     return ap.parse_args()
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no job around it (WORLD_SIZE unset): start the N ranks ourselves, one
+    process per GPU, as the reference's launcher does (onmt/bin/train_wgan_wh.py:67-97 spawns one process per GPU;
+    onmt/utils/distributed.py:20-32 joins them over tcp://master).  This parent never initialises the GPU
+    (torch.cuda.device_count() does not on this image) and never exec()s: the ranks are fresh children of
+    `python -m torch.distributed.run`, rank 0's JSON line is relayed, a failing child makes the parent fail."""
+    import socket
+    import subprocess
+    n = args.gpus
+    if not args.dry_run_gloo:
+        have = torch.cuda.device_count()
+        if have < n:
+            raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s); refusing to report a %d-GPU line from "
+                             "fewer ranks" % (n, have, n))
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: RCCL across processes needs it on this driver
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    line = None
+    for out in proc.stdout:
+        if out.lstrip().startswith("{"):
+            line = out.strip()
+        else:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit("bench.py: the %d-rank job exited with status %d" % (n, rc))
+    if line is None:
+        raise SystemExit("bench.py: the %d-rank job printed no result line" % n)
+    print(line)
+
+
+def dry_run_gloo(args):
+    """Launcher rehearsal (CPU): every rank joins a gloo group and adds itself to a census."""
+    import torch.distributed as dist
+    from mssrnet_style_transfer_amd.parallel import init_distributed
+    rank, local_rank, world = init_distributed(backend="gloo")
+    census = torch.zeros(max(world, 1))
+    census[rank] = 1.0
+    if world > 1:
+        dist.all_reduce(census)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "joined": int(census.sum()),
+                          "rccl": {"backend": dist.get_backend() if world > 1 else None,
+                                   "world_size": dist.get_world_size() if world > 1 else 1}}))
+    if world > 1:
+        dist.destroy_process_group()
 
 
 def roofline(records, dtype, workload="wgan"):
@@ -68,9 +125,9 @@ def roofline(records, dtype, workload="wgan"):
         ach, peak, unit, bound = a["bytes"] / sec / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
     else:
         ach, peak, unit, bound = a["flops"] / sec / 1e12, MFMA_PEAK_TFLOPS[key], "TFLOP/s", "mfma"
-    traffic, src = pmc_traffic(name, workload)
+    traffic, src, stale = pmc_traffic(name, workload)
     return dict(bound=bound, achieved=round(ach, 2), peak=peak, unit=unit, frac=round(ach / peak, 5), traffic=traffic,
-                traffic_source=src,
+                traffic_source=src, traffic_stale=stale,
                 kernel=name, launches_per_step=a["launches"], avg_launch_us=round(a["ms"] * 1e3 / a["launches"], 2),
                 algorithmic_bytes_per_launch=int(a["bytes"] / a["launches"]),
                 gemm_time_share={k: round(v["ms"], 3) for k, v in sorted(agg.items())})
@@ -126,19 +183,29 @@ def pmc_traffic(kernel, workload):
     (profiles/rNN_pmc_traffic.json, written by tools/pmc_traffic.py from the FETCH_SIZE and WRITE_SIZE passes --
     separate runs, FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes).  PMC counters cannot be read
     from inside the process, so the figure is the profiled one of the newest round on file; None when no summary
-    covers this kernel / workload."""
+    covers this kernel / workload.  The summary records a hash of the sources it was collected on
+    (tools/pmc_traffic.py source_sha16); when the running tree differs, the figure is withheld (traffic = None) and
+    `traffic_stale` says which file holds the outdated one."""
     import glob
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from pmc_traffic import source_sha16
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), reverse=True):
         with open(path) as f:
             t = json.load(f)
         k = t.get("workloads", {}).get(workload, {}).get(kernel)
         if k:
-            return int(k["traffic_bytes_per_launch"]), os.path.basename(path)
-    return None, None
+            if t.get("source_sha16", {}).get(workload) != source_sha16(ROOT):
+                return None, os.path.basename(path), True
+            return int(k["traffic_bytes_per_launch"]), os.path.basename(path), False
+    return None, None, None
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return launch_ranks(args)                 # before anything touches the GPU
+    if args.dry_run_gloo:
+        return dry_run_gloo(args)
     from mssrnet_style_transfer_amd import ops
     from mssrnet_style_transfer_amd.config import MSSRConfig
     from mssrnet_style_transfer_amd.parallel import GradSync, init_distributed
@@ -148,7 +215,7 @@ def main():
     import torch.distributed as dist
 
     rank, local_rank, world = init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no CPU fallback exists for the product path")
@@ -271,6 +338,8 @@ def main():
                        "tokens_per_step_per_gpu": tokens_per_step,
                        "parallelism": "dp%d (batch-sharded, bucketed RCCL grad all-reduce)" % world,
                        "losses": {k: round(v, 4) for k, v in {**logs[0], **logs[1]}.items()}},
+            "rccl": {"backend": dist.get_backend() if world > 1 else None,
+                     "world_size": dist.get_world_size() if world > 1 else 1},
             "roofline": roof, "algorithmic": algorithmic(wl, args, world, elapsed / args.steps, args.dtype),
             "cpu_baseline": cpu}
         print(json.dumps(out))

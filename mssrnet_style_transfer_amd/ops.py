@@ -126,10 +126,10 @@ def cast(t):
     if t.dtype == cd:
         return t
     if isinstance(t, torch.nn.Parameter):
-        key = id(t)
+        key = (id(t), cd)                   # one slot per (parameter, compute dtype): fp32 islands do not evict bf16
         hit = _cast_cache.get(key)
-        ver = (t._version, _param_epoch.get(key, 0))
-        if hit is not None and hit[0]() is t and hit[1] == ver and hit[2] == t.data_ptr() and hit[3].dtype == cd:
+        ver = (t._version, _param_epoch.get(id(t), 0))
+        if hit is not None and hit[0]() is t and hit[1] == ver and hit[2] == t.data_ptr():
             return hit[3]
         c = t.detach().to(cd)
         _cast_cache[key] = (weakref.ref(t), ver, t.data_ptr(), c)

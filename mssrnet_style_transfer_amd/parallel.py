@@ -40,6 +40,8 @@ class GradSync:
         self._hooks = []
         self._stream = None
         self._in_hook = False   # True while a gradient hook (autograd thread) runs: nothing there may block the host
+        import os
+        self._check = os.environ.get("MSSR_DP_CHECK", "0") not in ("", "0")
 
     # ---------------------------------------------------------------- bucket plan
     def _plan(self, module):
@@ -77,7 +79,7 @@ class GradSync:
             flat = torch.zeros(n, dtype=torch.float32, device=ps[0].device)
             views = [flat[off:off + p.numel()].view_as(p) for off, p in zip(offs, ps)]
             plan.append(dict(params=ps, flat=flat, views=views, ready=0, launched=False, armed=False, hooked=hooked,
-                             scaled=False, tables=None))
+                             scaled=False, tables=None, absent=[False] * len(ps)))
         self._plans[id(module)] = plan
         # gradient hooks are registered ONCE (registering and removing ~400 of them per phase cost ~2 ms of host
         # time per step); they only count while their bucket is armed
@@ -112,6 +114,12 @@ class GradSync:
         also pre-divides by the world size, so the reduced sum IS the mean; elsewhere (CPU tensors under gloo) one
         torch multi-tensor copy."""
         grads = [p.grad for p in b["params"]]
+        # Parameters without a gradient in this phase stay without one after the reduction (their zero slice is
+        # reduced, not handed out): torch.optim.Adam / optim.Adam skip grad-None parameters -- no moment decay, no
+        # step count -- and data-parallel training must do the same as a single process.  The autograd graph of a
+        # phase is the same on every rank (same code, same phase), so the set is too; MSSR_DP_CHECK=1 verifies it
+        # with one small collective per sync.
+        b["absent"] = [g is None for g in grads]
         if b["flat"].is_cuda and all(g is None or (g.dtype == torch.float32 and g.is_contiguous() and g.is_cuda
                                                    and g.data_ptr() % 16 == 0) for g in grads):
             import ctypes
@@ -177,6 +185,18 @@ class GradSync:
         p = next(module.parameters(), None)
         return not (p is not None and p.is_cuda and dist.get_backend(self.group) == "gloo")
 
+    def _check_presence(self):
+        """MSSR_DP_CHECK=1: every rank must have left the same parameters without a gradient (blocking; debug only)."""
+        mine = torch.tensor([float(a) for b, _ in self._pending for a in b["absent"]])
+        dev = self._pending[0][0]["flat"].device if self._pending else torch.device("cpu")
+        if dist.get_backend(self.group) != "gloo":
+            mine = mine.to(dev)
+        tot = mine.clone()
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM, group=self.group)
+        bad = ((tot != 0) & (tot != self.world)).nonzero().flatten().tolist()
+        if bad:
+            raise RuntimeError("GradSync: ranks disagree on which parameters have no gradient (flat indices %s)" % bad[:8])
+
     def arm(self, module):
         """Hook the next backward through ``module``: buckets are reduced as they fill."""
         if not self.active or not self._overlap_ok(module):
@@ -200,6 +220,8 @@ class GradSync:
         for b, work in self._pending:
             if work is not None:
                 work.wait()
+        if self._check and self.world > 1:
+            self._check_presence()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
         inv = 1.0 / self.world
@@ -211,8 +233,13 @@ class GradSync:
             # filled again, i.e. until the next backward of these parameters has finished -- by then zero_grad() has
             # dropped them (or, if the caller accumulates without zero_grad, autograd has added into them in place and
             # _fill's copy is a copy onto itself).
-            for v, p in zip(b["views"], b["params"]):
-                p.grad = v
+            for v, p, absent in zip(b["views"], b["params"], b["absent"]):
+                if absent:
+                    p.grad = None
+                elif p.dtype == torch.float32:
+                    p.grad = v
+                else:                                   # buckets are fp32; a parameter of another dtype gets a copy
+                    p.grad = v.to(p.dtype)
             b["ready"], b["launched"] = 0, False
         self._pending = []
 

@@ -27,6 +27,7 @@ def _net():
 def _worker(rank, world, port, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
+    os.environ["MSSR_DP_CHECK"] = "1"                  # ranks must agree on which parameters have no gradient
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from mssrnet_style_transfer_amd.parallel import GradSync
     res = {}
@@ -45,7 +46,14 @@ def _worker(rank, world, port, out):
         early = len(sync._pending)                     # collectives already launched from gradient hooks
         assert early == (2 if mode == "armed" else 0), (mode, early)
         sync([net])
-        res[mode] = (local, [None if p.grad is None else p.grad.clone() for p in net.parameters()])
+        reduced = [None if p.grad is None else p.grad.clone() for p in net.parameters()]
+        # a parameter unused in this phase must not be touched by the optimizer (torch's Adam skips grad None; a
+        # zero gradient would still decay its moments and advance its step count): seed non-zero moments first
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+        for p in net[5].parameters():
+            opt.state[p] = dict(step=torch.tensor(3.0), exp_avg=torch.full_like(p, 0.5), exp_avg_sq=torch.full_like(p, 0.25))
+        opt.step()
+        res[mode] = (local, reduced, [p.detach().clone() for p in net.parameters()])
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
     dist.destroy_process_group()
 
@@ -59,13 +67,30 @@ def test_grad_sync_two_ranks(tmp_path):
         for i in range(n):
             locs = [r[k][mode][0][i] for k in range(world)]
             if locs[0] is None:
-                for k in range(world):      # never received a gradient: reduced value is zero
-                    g = r[k][mode][1][i]
-                    assert g is None or float(g.abs().max()) == 0.0
+                for k in range(world):      # never received a gradient: none after the reduction either
+                    assert r[k][mode][1][i] is None, (mode, i, k)
                 continue
             want = sum(locs) / world
             for k in range(world):
                 assert torch.allclose(r[k][mode][1][i], want, rtol=1e-6, atol=1e-7), (mode, i, k)
+
+
+    # world = 2 against world = 1 on the mean gradients: same parameters after Adam, the unused layer unmoved
+    for mode in ("plain", "armed"):
+        net = _net()
+        before = [p.detach().clone() for p in net.parameters()]
+        for i, p in enumerate(net.parameters()):
+            g = r[0][mode][1][i]
+            p.grad = None if g is None else g.clone()
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2)
+        for p in net[5].parameters():
+            opt.state[p] = dict(step=torch.tensor(3.0), exp_avg=torch.full_like(p, 0.5), exp_avg_sq=torch.full_like(p, 0.25))
+        opt.step()
+        for i, p in enumerate(net.parameters()):
+            for k in range(world):
+                assert torch.equal(r[k][mode][2][i], p.detach()), (mode, i, k)
+        for p, b in zip(list(net.parameters())[-2:], before[-2:]):
+            assert torch.equal(p.detach(), b)
 
 
 def test_single_rank_is_a_noop():

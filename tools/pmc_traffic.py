@@ -58,6 +58,23 @@ def read(path, counter):
     return out
 
 
+def source_sha16(root):
+    """Hash of everything that decides which kernels a bench step launches and what they do (kernel sources, the
+    C ABI header, the Python host path, bench.py): bench.py recomputes it and flags `traffic` as stale when the tree
+    it runs from is not the tree these counters were collected on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, "mssrnet_style_transfer_amd", "csrc", "*.h*")) +
+                   glob.glob(os.path.join(root, "mssrnet_style_transfer_amd", "**", "*.py"), recursive=True) +
+                   [os.path.join(root, "include", "mssr_hip.h"), os.path.join(root, "bench.py")])
+    for f in files:
+        h.update(os.path.relpath(f, root).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def main():
     workload, fetch_csv, write_csv, out_json = sys.argv[1:5]
     fetch, write = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
@@ -82,6 +99,9 @@ def main():
                            "bench.py kernel name (tools/pmc_traffic.py)")
     doc.setdefault("workloads", {})[workload] = kernels
     doc.setdefault("sources", {})[workload] = [os.path.basename(fetch_csv), os.path.basename(write_csv)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    # the counters must be parsed from the tree they were collected on (collect, then `copy`, before editing anything)
+    doc.setdefault("source_sha16", {})[workload] = source_sha16(root)
     with open(out_json, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
     for k, v in kernels.items():
