@@ -780,6 +780,19 @@ def gen_long():
     return out
 
 
+def gen_long_readme():
+    """Config 5's LENGTH (64..128-word sentences: T = 130 teacher-forced rows, 130 / 140 decode steps, attention over
+    more than 64 keys) at the README WIDTHS (d512 = 8 x 64, ff 1024, V = 9606, critics / style generator / teacher at
+    their real widths), 2 main layers, 4 sentences, dropout 0: the bf16 bar of north_star (2e-2) is tested on the
+    layer widths the stress configuration really runs, not on 32..64-wide toy layers."""
+    cfg = readme_cfg()
+    batch = make_batch(4, 128, cfg.vocab_size, seed=43, min_words=64)
+    out = dict(net_seed=520, batch_seed=43, batch_size=4, max_words=128, min_words=64,
+               cfg=dict(layers=2, dropout=0.0, attention_dropout=0.0))
+    out.update(run_phases(cfg, batch, 520, ("discriminator", "generator", "reconstruct")))
+    return out
+
+
 def decisive_generator(model, cfg, alpha, perm_seed):
     """Random weights give near-uniform, near-tied next-token distributions (top-2 margins of a few 1e-3 of the logit
     scale: coin flips at ANY precision below fp32), unlike a trained model.  Add a trained-like decisive component to
@@ -879,7 +892,7 @@ def main():
     meta = dict(torch=str(torch.__version__), note="generated from /root/reference by tests/golden/make_golden.py")
     for name in which:
         data = {"ops": gen_ops, "modules": gen_modules, "phases": gen_phases, "greedy": gen_greedy, "readme": gen_readme,
-                "long": gen_long, "greedy_big": gen_greedy_big}[name]()
+                "long": gen_long, "long_readme": gen_long_readme, "greedy_big": gen_greedy_big}[name]()
         data["_meta"] = meta
         path = os.path.join(HERE, name + ".pt")
         torch.save(data, path)

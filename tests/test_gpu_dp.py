@@ -1,4 +1,4 @@
-"""Data-parallel WGAN phases on the GPU kernels: two ranks (both on cuda:0, gloo transport, so it runs on a
+"""Data-parallel WGAN step (Trainer.train_wgan_step, as bench.py --gpus N runs it) on the GPU kernels: two ranks (both on cuda:0, gloo transport, so it runs on a
 one-GPU box), each with its own batch; after the phase every rank's gradients must equal the mean over ranks
 of the gradients a single process computes for the same two batches (SUM then / world)."""
 import os
@@ -38,6 +38,19 @@ def _grads(nets, names):
             for n in names}
 
 
+def _wgan_step(tr, nets, b):
+    """One Trainer.train_wgan_step -- the call `bench.py --gpus N` runs on every rank (shared decode sweep) -- ->
+    {"D": critic gradients as the D half left them, "G": generator-side gradients}."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from helpers import wgan_step_with_capture
+    assert tr.cfg.share_decode_sweep and tr.cfg.batch_generator_phase and tr.cfg.ap_gen_self_style_text
+    torch.manual_seed(7)
+    _, _, d_grads = wgan_step_with_capture(tr, b, nets)
+    return {"D": {n: {k: (None if g is None else g.cpu()) for k, g in d.items()} for n, d in d_grads.items()},
+            "G": _grads(nets, ("model", "style_generator"))}
+
+
 def _worker(rank, world, port, out):
     import faulthandler
     faulthandler.dump_traceback_later(90, exit=True)        # a stuck rank names its stack instead of hanging the run
@@ -48,13 +61,7 @@ def _worker(rank, world, port, out):
     from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
     cfg, nets, b = _setup(100 + rank)
     tr = Trainer(nets, cfg, grad_sync=GradSync(world, bucket_bytes=1 << 16))
-    res = {}
-    torch.manual_seed(7)
-    tr.train_discriminator(b)
-    res["D"] = _grads(nets, ("text_discriminator", "style_discriminator"))
-    torch.manual_seed(7)
-    tr.train_generator(b)
-    res["G"] = _grads(nets, ("model", "style_generator"))
+    res = _wgan_step(tr, nets, b)
     torch.save(res, os.path.join(out, "rank%d.pt" % rank))
     dist.destroy_process_group()
     faulthandler.cancel_dump_traceback_later()
@@ -69,14 +76,7 @@ def test_data_parallel_phases_match_mean_of_single_process_gradients(tmp_path):
     for r in range(world):
         cfg, nets, b = _setup(100 + r)
         tr = Trainer(nets, cfg)
-        one = {}
-        torch.manual_seed(7)
-        tr.train_discriminator(b)
-        one["D"] = _grads(nets, ("text_discriminator", "style_discriminator"))
-        torch.manual_seed(7)
-        tr.train_generator(b)
-        one["G"] = _grads(nets, ("model", "style_generator"))
-        ref.append(one)
+        ref.append(_wgan_step(tr, nets, b))
     checked = 0
     for phase in ("D", "G"):
         for net in ref[0][phase]:
@@ -112,15 +112,10 @@ def _nccl_worker(rank, port, out):
     tr = Trainer(nets, cfg, grad_sync=sync)
     assert sync.active
     res = {}
-    for step in range(3):                                  # several steps back to back: no host sync in between
+    res = _wgan_step(tr, nets, b)
+    for step in range(2):                                  # more steps back to back: no host sync in between
         torch.manual_seed(7)
-        d = tr.train_discriminator(b)
-        if step == 0:
-            res["D"] = _grads(nets, ("text_discriminator", "style_discriminator"))
-        torch.manual_seed(7)
-        g = tr.train_generator(b)
-        if step == 0:
-            res["G"] = _grads(nets, ("model", "style_generator"))
+        d, g = tr.train_wgan_step(b)
     res["logs"] = {**d, **g}
     torch.cuda.synchronize()
     torch.save(res, os.path.join(out, "nccl.pt"))
@@ -137,14 +132,9 @@ def test_rccl_path_single_rank_identity_reduction(tmp_path):
     from mssrnet_style_transfer_amd.trainer_wgan_wh import Trainer
     cfg, nets, b = _setup(100)
     tr = Trainer(nets, cfg)
-    torch.manual_seed(7)
-    tr.train_discriminator(b)
-    ref_d = _grads(nets, ("text_discriminator", "style_discriminator"))
-    torch.manual_seed(7)
-    tr.train_generator(b)
-    ref_g = _grads(nets, ("model", "style_generator"))
+    one = _wgan_step(tr, nets, b)
     n = 0
-    for phase, ref in (("D", ref_d), ("G", ref_g)):
+    for phase, ref in (("D", one["D"]), ("G", one["G"])):
         for net in ref:
             # float atomics (embedding / column-sum gradients) make two runs differ in the last bits
             floor = 1e-6 * max(float(g.abs().max()) for g in ref[net].values() if g is not None)
