@@ -520,9 +520,18 @@ int mssr_decode_step_fwd(const mssr_decode_plan* plan, int step, void* stream);
  * slabs (the caller contracts them with the saved activations into parameter gradients, one
  * product per parameter over all steps) and the context-attention score gradients in ds_ctx. */
 int mssr_decode_step_bwd(const mssr_decode_plan* plan, int step, void* stream);
-/* All steps in one call. */
+/* All steps in one call (the T-iteration loop of onmt/train_and_translate.py:202-231 and its reverse).
+ * Replay: a sweep's ~2 800 launches depend only on the plan's contents; the second time a plan with the same
+ * contents (every field but `seed`, and the layer table) arrives on a stream, its launches are recorded as a hipGraph
+ * and from then on the call is one seed store + one hipGraphLaunch (0.9 ms of host time instead of ~9 ms) with the
+ * same launches and bit-identical results; the per-call dropout seed is read by the recorded kernels from a device
+ * word.  Plans whose buffers move from call to call never match and run eagerly, as do calls made while the caller
+ * captures the stream itself or records profiles (mssr_prof_start).  MSSR_DECODE_GRAPH=0 disables the mechanism.
+ * At most 16 recordings are kept (least recently used is dropped).  No device memory is allocated. */
 int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);
 int mssr_decode_bwd(const mssr_decode_plan* plan, void* stream);
+/* Number of recorded sweeps currently kept (diagnostics, tests).  No reference counterpart. */
+int mssr_decode_graphs(void);
 /* Gradient of the memory keys | values of a decode sweep, all layers in one launch: contracts the per-step slabs the
  * backward sweep left in plan.ds_ctx [n_layers][2 = ds|pd][T][B*heads][Ls] (float) with the saved context queries
  * (qc: layer l at qc + l*qc_layer_stride elements, [T][B, d]) and context gradients (dctx, likewise) over the steps:

@@ -160,6 +160,7 @@ SIGNATURES = {
     "mssr_decode_step_bwd": ([POINTER(DecodePlan), _I, _P], c_int),
     "mssr_decode_fwd": ([POINTER(DecodePlan), _P], c_int),
     "mssr_decode_bwd": ([POINTER(DecodePlan), _P], c_int),
+    "mssr_decode_graphs": ([], c_int),
     "mssr_ctx_kv_grad": ([_P, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
 }
 

@@ -19,6 +19,7 @@ void prof_end(int i, hipStream_t s, int kernel, int in_dt, int out_dt, int tile,
 // it to hipExtLaunchKernelGGL, which stamps the events with the dispatch's own begin / end times (the same
 // clock rocprofv3's kernel trace reads), so a record holds the kernel alone and not the markers around it.
 bool prof_take(hipEvent_t* start, hipEvent_t* stop);
+bool prof_active();     // mssr_prof_start() .. mssr_prof_stop(): launches carry events, nothing may be replayed from a graph
 template <typename... KArgs, typename... Args>
 inline void klaunch(void (*kern)(KArgs...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, Args... args) {
     hipEvent_t e0, e1;

@@ -34,6 +34,7 @@ int prof_begin(hipStream_t s) {
     tl_armed = i;
     return i;
 }
+bool prof_active() { return g_prof.on; }
 bool prof_take(hipEvent_t* start, hipEvent_t* stop) {
     if (tl_armed < 0) return false;
     ProfState& P = g_prof;

@@ -16,6 +16,11 @@
 #include <stdlib.h>
 #include <thread>
 #include <initializer_list>
+#include <mutex>
+#include <string>
+#include <vector>
+#include <functional>
+#include <string.h>
 
 namespace mssr {
 
@@ -30,7 +35,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void attn_step_fwd_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
-    int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0) {
+    int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0,
+    const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;
     __shared__ float sc[4][AT_MAXK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bh_raw = blockIdx.x * 4 + wave;
@@ -114,7 +121,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
     T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
-    int bh_off) {
+    int bh_off, const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;
     __shared__ float s_p[4][AT_MAXK];      // p, then ds
     __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p); then the gathered ds coefficients of later steps
     __shared__ float s_pd[4][AT_MAXK];     // dropped p; then the gathered pd coefficients of later steps
@@ -340,7 +348,9 @@ template <typename T, int LS, int AT_NL>
 __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
-    int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0) {
+    int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0,
+    const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -436,7 +446,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
     T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
-    int bh_off) {
+    int bh_off, const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -660,7 +671,9 @@ __global__ __launch_bounds__(256) void ctx_kv_grad_kernel(const float* __restric
 template <typename T>
 __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict__ e, const float* __restrict__ pe,
                                                              T* __restrict__ out, int rows, int d, int step, float s,
-                                                             float p, uint64_t seed, int drop_row0) {
+                                                             float p, uint64_t seed, int drop_row0,
+                                                             const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;
     const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t thr = drop_thr16(p);
     const int64_t n = (int64_t)rows * d;
@@ -808,10 +821,15 @@ struct Ctx : GemmCtx {
     int b0, Bc, chunk;
     int eval_rows;      // forward: rows of this chunk below it skip dropout (mixed eval / train sweep)
     int hash_row_off;   // backward over a row slice of an unchunked forward: offset of the slice in the forward's rows
+    // dropout seed of the call = seed_val + *seed_base (seed_base null: seed_val alone).  Eager sweeps carry the plan's
+    // seed by value; a sweep recorded for hipGraph replay carries 0 and reads the seed from memory, so one recording
+    // serves every later call of the same plan shape
+    uint64_t seed_val;
+    const uint64_t* seed_base;
 };
 
 static inline uint64_t site_seed(const Ctx& c, int step, int layer, int site) {
-    return c.p->seed + (uint64_t)step * 0x100000001B3ull + (uint64_t)(layer + 1) * 0x9E3779B1ull +
+    return c.seed_val + (uint64_t)step * 0x100000001B3ull + (uint64_t)(layer + 1) * 0x9E3779B1ull +
            (uint64_t)site * 7919ull + (uint64_t)c.chunk * 0xC2B2AE3D27D4EB4Full;
 }
 
@@ -848,7 +866,7 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
 #define MSSR_FWD_TILED_N(LS, NL)                                                                                    \
     attn_step_fwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh, \
-        Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows)
+        Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows, c.seed_base)
 #define MSSR_FWD_TILED(LS)                            \
     do {                                              \
         if (Lk <= 4 * (64 >> LS)) MSSR_FWD_TILED_N(LS, 4); \
@@ -865,7 +883,7 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
 #undef MSSR_FWD_TILED_N
     attn_step_fwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (T*)ctx, ctx_bs, c.Bc, p->heads, dh,
-        Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows);
+        Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows, c.seed_base);
 }
 
 template <typename T>
@@ -883,7 +901,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     attn_step_bwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,    \
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,  \
-        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads)
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads, c.seed_base)
 #define MSSR_BWD_TILED(LS)                                                              \
     do {                                                                                \
         const int need = gather && p->T - step > Lk ? p->T - step : Lk;                 \
@@ -902,7 +920,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,
-        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads);
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads, c.seed_base);
 }
 
 #define DT_CALL(c, fn, ...)                                   \
@@ -1029,10 +1047,10 @@ static int step_fwd(const Ctx& c, int step) {
         const unsigned g = (unsigned)((Rd / 4 + 255) / 256);
         if (c.dt == MSSR_F32)
             embed_epilogue_kernel<float><<<g, 256, 0, c.s>>>((const float*)G.tmp(), p->pe, (float*)G.X(0), R, d, step,
-                                                             sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows);
+                                                             sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows, c.seed_base);
         else
             embed_epilogue_kernel<bf16><<<g, 256, 0, c.s>>>((const bf16*)G.tmp(), p->pe, (bf16*)G.X(0), R, d, step,
-                                                            sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows);
+                                                            sqrtf((float)d), pd, site_seed(c, step, -1, 0), c.eval_rows, c.seed_base);
     }
     }
     for (int l = 0; l < NL; ++l) {
@@ -1161,11 +1179,11 @@ static int step_bwd(const Ctx& c, int step) {
         if (c.dt == MSSR_F32)
             ln_bwd_dx_kernel<float><<<(R + 3) / 4, 256, 0, c.s>>>((const float*)dy, (const float*)x, g, G.stat(idx, 0),
                                                                  G.stat(idx, 1), (const float*)dres, (float*)dx,
-                                                                 (float*)dx2, R, d, pd, seed, extra, c.hash_row_off);
+                                                                 (float*)dx2, R, d, pd, seed, extra, c.hash_row_off, c.seed_base);
         else
             ln_bwd_dx_kernel<bf16><<<(R + 3) / 4, 256, 0, c.s>>>((const bf16*)dy, (const bf16*)x, g, G.stat(idx, 0),
                                                                 G.stat(idx, 1), (const bf16*)dres, (bf16*)dx,
-                                                                (bf16*)dx2, R, d, pd, seed, extra, c.hash_row_off);
+                                                                (bf16*)dx2, R, d, pd, seed, extra, c.hash_row_off, c.seed_base);
     };
 
     // softmax backward: dlogits[step] (compute dtype, padded columns stay zero)
@@ -1322,7 +1340,7 @@ static StreamPool* pool_for_current_device() {
 
 // Runs steps [s_begin, s_end) (forward) or the same range downwards (backward) for every chunk.
 static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool backward, hipStream_t stream,
-                     const char* who) {
+                     const char* who, const uint64_t* seed_base = nullptr) {
     if (int e = check_plan(p, s_begin, who)) return e;
     MSSR_REQUIRE(s_end > s_begin && s_end <= p->T, "%s: bad step range", who);
     if (backward) {
@@ -1349,6 +1367,8 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
         c.b0 = row0 + i * per; c.Bc = (c.b0 + per <= p->B) ? per : p->B - c.b0; c.chunk = i;
         c.eval_rows = backward ? 0 : p->eval_rows;
         c.hash_row_off = row0;
+        c.seed_val = seed_base ? 0 : p->seed;
+        c.seed_base = seed_base;
         c.ws = p->gemm_ws ? (char*)p->gemm_ws + i * ws_each : nullptr;
         c.ws_bytes = ws_each;
         c.s = stream;
@@ -1357,6 +1377,12 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
             (void)hipStreamWaitEvent(c.s, P->fork, 0);
         }
     }
+    // every GEMM descriptor filled on this thread while the sweep is issued adds the same word to its seeds
+    struct SeedBaseGuard {
+        const uint64_t* prev;
+        explicit SeedBaseGuard(const uint64_t* b) : prev(tl_seed_base) { tl_seed_base = b; }
+        ~SeedBaseGuard() { tl_seed_base = prev; }
+    } seed_guard(seed_base);
     int rc = MSSR_OK;
     // steps from late_step on cover sentences [late_row0, B) only: backward (the others' gradients are zero there)
     // and, with late_fwd, forward too (their decodes have ended).  Dropout decisions are indexed by the row inside the
@@ -1402,6 +1428,7 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
         for (int i = 1; i < nch; ++i)
             th[i] = std::thread([&, i]() {
                 (void)hipSetDevice(dev);
+                tl_seed_base = seed_base;
                 rcs[i] = run_chunk(i);
                 snprintf(msgs[i], sizeof(msgs[i]), "%s", mssr_last_error());
             });
@@ -1422,9 +1449,147 @@ static int run_steps(const mssr_decode_plan* p, int s_begin, int s_end, bool bac
     return rc;
 }
 
+// ------------------------------------------------------------------ whole sweeps as hipGraphs
+// A sweep is ~2 800 launches that the host issues in ~9 ms (3.3 us each) and the GPU runs in ~17 ms: with two sweeps
+// per WGAN step the host spends 40 % of a step inside these two calls and the step is host-bound.  A sweep's launches
+// depend only on the plan (pointers, sizes, flags): everything that changes from call to call is the dropout seed,
+// which recorded sweeps read from a device word (Ctx::seed_base).  So the SECOND time a plan with the same contents
+// arrives on a stream, its launches are recorded once (stream capture on a stream of the library's own: the caller's
+// may be the legacy default stream, which cannot be captured) and from then on the call is: one tiny kernel that
+// stores the seed + hipGraphLaunch -- 0.9 ms of host time (tools/graph_host_bench.py), identical launches, identical
+// bits (tests/test_gpu_decode_engine.py).  Plans whose buffers move between calls simply never match and stay eager;
+// MSSR_DECODE_GRAPH=0 switches the mechanism off.  Nothing is allocated: the seed words live in a static device array.
+constexpr int GRAPH_SLOTS = 16;                    // recorded sweeps kept per process (least recently used goes)
+static __device__ __align__(16) uint64_t graph_seed_words[GRAPH_SLOTS * 2];     // one 16-byte line part per slot
+
+__global__ void graph_seed_kernel(uint64_t* word, uint64_t seed) { *word = seed; }
+
+struct SweepGraph {
+    bool used = false;
+    std::string key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    uint64_t stamp = 0;
+};
+struct GraphCache {
+    std::mutex mu;
+    SweepGraph slot[GRAPH_SLOTS];
+    uint64_t* words[16] = {};                      // device address of graph_seed_words, per device
+    hipStream_t cap_stream[16] = {};
+    std::vector<size_t> seen;                      // hashes of plans met once (recorded at the second meeting)
+    uint64_t clock = 0;
+};
+static GraphCache g_graphs;
+
+static std::string sweep_key(const mssr_decode_plan* p, bool backward, hipStream_t stream, int dev) {
+    mssr_decode_plan q = *p;
+    q.seed = 0;
+    std::string k(reinterpret_cast<const char*>(&q), sizeof(q));
+    k.append(reinterpret_cast<const char*>(p->layers), sizeof(mssr_dec_layer) * (size_t)p->n_layers);
+    const uintptr_t tail[3] = {(uintptr_t)stream, (uintptr_t)dev, (uintptr_t)(backward ? 1 : 0)};
+    k.append(reinterpret_cast<const char*>(tail), sizeof(tail));
+    return k;
+}
+
+// true: the sweep was launched from a recorded graph (rc holds the result); false: the caller runs it eagerly
+static bool run_sweep_graphed(const mssr_decode_plan* p, bool backward, hipStream_t stream, const char* who, int& rc) {
+    static const bool enabled = [] { const char* e = getenv("MSSR_DECODE_GRAPH"); return !e || atoi(e) != 0; }();
+    if (!enabled || prof_active() || !p || !p->layers || p->n_layers <= 0 || p->n_chunks != 1) return false;
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return false;
+    if (check_plan(p, 0, who) != MSSR_OK) return false;            // the eager path reports the error
+    GraphCache& C = g_graphs;
+    std::lock_guard<std::mutex> lock(C.mu);
+    if (!C.words[dev]) {
+        void* w = nullptr;
+        if (hipGetSymbolAddress(&w, HIP_SYMBOL(graph_seed_words)) != hipSuccess || !w) return false;
+        C.words[dev] = (uint64_t*)w;
+        if (hipStreamCreateWithFlags(&C.cap_stream[dev], hipStreamNonBlocking) != hipSuccess) { C.words[dev] = nullptr; return false; }
+    }
+    const std::string key = sweep_key(p, backward, stream, dev);
+    static const bool debug = [] { const char* e = getenv("MSSR_DECODE_GRAPH_DEBUG"); return e && atoi(e) != 0; }();
+    if (debug) {            // which bytes of the plan moved since the last sweep of this direction
+        static std::string last[2];
+        std::string& prev = last[backward ? 1 : 0];
+        if (prev.size() == key.size()) {
+            int nd = 0;
+            char buf[256];
+            int o = snprintf(buf, sizeof(buf), "[mssr] %s plan vs previous:", who);
+            for (size_t i = 0; i + 8 <= key.size(); i += 8)
+                if (memcmp(&key[i], &prev[i], 8) != 0 && ++nd <= 12) o += snprintf(buf + o, sizeof(buf) - o, " +%zu", i);
+            fprintf(stderr, "%s (%d words differ of %zu; plan struct %zu bytes)\n", buf, nd, key.size() / 8, sizeof(mssr_decode_plan));
+        }
+        prev = key;
+    }
+    int hit = -1, victim = 0;
+    for (int i = 0; i < GRAPH_SLOTS; ++i) {
+        if (C.slot[i].used && C.slot[i].key == key) { hit = i; break; }
+        if (!C.slot[i].used) victim = i;
+        else if (C.slot[victim].used && C.slot[i].stamp < C.slot[victim].stamp) victim = i;
+    }
+    if (hit < 0) {
+        const size_t h = std::hash<std::string>()(key);
+        bool met = false;
+        for (size_t v : C.seen) met = met || v == h;
+        if (!met) {                                 // first meeting: eager, remember it
+            if (C.seen.size() >= 64) C.seen.erase(C.seen.begin());
+            C.seen.push_back(h);
+            return false;                           // (building and hashing the 1.5 KB key costs microseconds)
+        }
+        SweepGraph& S = C.slot[victim];
+        if (S.used) {                               // a replay of the evicted recording may still be running
+            (void)hipDeviceSynchronize();
+            (void)hipGraphExecDestroy(S.exec);
+            (void)hipGraphDestroy(S.graph);
+            S = SweepGraph();
+        }
+        hipStream_t cs = C.cap_stream[dev];
+        if (hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed) != hipSuccess) { (void)hipGetLastError(); return false; }
+        const int r = run_steps(p, 0, p->T, backward, cs, who, C.words[dev] + 2 * victim);
+        hipGraph_t g = nullptr;
+        const hipError_t ee = hipStreamEndCapture(cs, &g);
+        if (r != MSSR_OK || ee != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            if (r != MSSR_OK) { rc = r; return true; }        // an argument error: report it, nothing ran
+            return false;
+        }
+        hipGraphExec_t ex = nullptr;
+        if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess || !ex) {
+            (void)hipGraphDestroy(g);
+            (void)hipGetLastError();
+            return false;
+        }
+        S.used = true; S.key = key; S.graph = g; S.exec = ex;
+        hit = victim;
+    }
+    SweepGraph& S = C.slot[hit];
+    S.stamp = ++C.clock;
+    graph_seed_kernel<<<1, 1, 0, stream>>>(C.words[dev] + 2 * hit, p->seed);
+    if (hipGraphLaunch(S.exec, stream) != hipSuccess) {
+        set_error("%s: hipGraphLaunch failed: %s", who, hipGetErrorString(hipGetLastError()));
+        rc = MSSR_ERR_LAUNCH;
+        return true;
+    }
+    rc = MSSR_OK;
+    return true;
+}
+
+// number of recorded sweeps alive (tests / tools)
+static int sweep_graph_count() {
+    std::lock_guard<std::mutex> lock(g_graphs.mu);
+    int n = 0;
+    for (const SweepGraph& s : g_graphs.slot) n += s.used ? 1 : 0;
+    return n;
+}
+
 }  // namespace mssr
 
 using namespace mssr;
+
+extern "C" int mssr_decode_graphs(void) { return sweep_graph_count(); }
 
 extern "C" int mssr_decode_step_fwd(const mssr_decode_plan* p, int step, void* stream) {
     MSSR_REQUIRE(p, "decode_step_fwd: null plan");
@@ -1441,11 +1606,15 @@ extern "C" int mssr_decode_step_bwd(const mssr_decode_plan* p, int step, void* s
 // from and join back into `stream`.
 extern "C" int mssr_decode_fwd(const mssr_decode_plan* p, void* stream) {
     MSSR_REQUIRE(p, "decode_fwd: null plan");
+    int rc = MSSR_OK;
+    if (run_sweep_graphed(p, false, (hipStream_t)stream, "decode_fwd", rc)) return rc;
     return run_steps(p, 0, p->T, false, (hipStream_t)stream, "decode_fwd");
 }
 
 extern "C" int mssr_decode_bwd(const mssr_decode_plan* p, void* stream) {
     MSSR_REQUIRE(p, "decode_bwd: null plan");
+    int rc = MSSR_OK;
+    if (run_sweep_graphed(p, true, (hipStream_t)stream, "decode_bwd", rc)) return rc;
     return run_steps(p, 0, p->T, true, (hipStream_t)stream, "decode_bwd");
 }
 

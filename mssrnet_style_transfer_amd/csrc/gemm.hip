@@ -241,6 +241,8 @@ static void launch(const GemmArgs& a0, int64_t batch0, hipStream_t s) {
 
 }  // namespace mssr
 
+thread_local const uint64_t* mssr::tl_seed_base = nullptr;
+
 using namespace mssr;
 
 extern "C" int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch) { return use_tile64(m, n, batch) ? 64 : 32; }
@@ -256,6 +258,7 @@ void mssr::gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
     a.a_bo = d->a_bo; a.a_bi = d->a_bi; a.b_bo = d->b_bo; a.b_bi = d->b_bi; a.c_bo = d->c_bo; a.c_bi = d->c_bi;
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
     a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.drop_row0 = d->drop_row0;
+    a.seed_base = tl_seed_base;
     a.k_seg_len = d->k_seg_len; a.k_seg_stride = d->k_seg_stride;
     a.ksplit = 1;
     a.partial = nullptr;

@@ -20,6 +20,10 @@ struct GemmArgs {
     int a_vec, b_vec;   // 16-B vector loads allowed for this operand
     float drop_p;       // > 0: dropout in the epilogue, keep = hash(seed, z*m*n + row*n + col) >= p*2^32
     uint64_t drop_seed;
+    // Optional device word ADDED to drop_seed and lnb_seed by the kernels (null: nothing added).  A decode sweep that
+    // is replayed as a hipGraph keeps the per-call seed there, so the captured kernel arguments never change
+    // (decode.hip: the by-value seeds then hold the site offsets only).
+    const uint64_t* seed_base;
     int64_t drop_row0;  // rows below this one are NOT dropped (and not rescaled): eval-mode rows sharing a launch
     int64_t k_seg_len, k_seg_stride;    // segmented reduction index (weight-gradient kernel only), 0 = plain
     float* partial;     // skinny split-K: fp32 slabs [ksplit][m][n]
@@ -48,6 +52,11 @@ struct GemmArgs {
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) {
     return keep16(seed, idx, drop_thr16(p));
 }
+// by-value seed + the word at seed_base (uniform: a scalar load)
+__device__ __forceinline__ uint64_t eff_seed(const GemmArgs& p, uint64_t s) { return p.seed_base ? s + *p.seed_base : s; }
+// the seed_base every GemmArgs filled on this thread receives (gemm_fill_args); set by the decode engine while it
+// records a sweep, null otherwise
+extern thread_local const uint64_t* tl_seed_base;
 
 // v = alpha*acc (+bias) ; relu ; dropout ; (+residual) ; gate ; (+beta*C_old)
 template <typename TI, typename TO>
@@ -56,7 +65,7 @@ __device__ __forceinline__ void epilogue_store(const GemmArgs& p, float acc, int
     float v = p.alpha * acc + bias;
     if (p.relu) v = fmaxf(v, 0.f);
     if (p.drop_p > 0.f && row >= p.drop_row0)
-        v = drop_keep(p.drop_seed, (uint64_t)(zoff + row * p.n + col), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+        v = drop_keep(eff_seed(p, p.drop_seed), (uint64_t)(zoff + row * p.n + col), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
     if (R) v += to_f(R[row * p.ldr + col]);
     if (G) v = to_f(G[row * p.ldg + col]) > 0.f ? v : 0.f;
     if (p.beta != 0.f) v += p.beta * to_f(C[row * p.ldc + col]);

@@ -110,6 +110,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     c2 /= (float)p.k;
     const float sc = p.lnb_extra / (1.0f - p.lnb_p);
     const uint32_t thr = drop_thr16(p.lnb_p);
+    const uint64_t lnb_seed = eff_seed(p, p.lnb_seed);
     const bool writer = blockIdx.x == 0 && row_ok;
     f32x4 acc[LNB_FN];
 #pragma unroll
@@ -124,7 +125,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
         if (p.lnb_p > 0.f) {
             const uint64_t i2 = (uint64_t)((ar + p.lnb_row_off) * p.k + k) >> 1;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) kp[q] = keep16_pair(p.lnb_seed, i2 + q, thr);
+            for (int q = 0; q < 4; ++q) kp[q] = keep16_pair(lnb_seed, i2 + q, thr);
         }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {

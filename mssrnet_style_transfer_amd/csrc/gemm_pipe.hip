@@ -266,7 +266,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
                 float x = p.alpha * v[e] + bias[e];
                 if (p.relu) x = fmaxf(x, 0.f);
                 if (p.drop_p > 0.f && grow >= p.drop_row0)
-                    x = drop_keep(p.drop_seed, (uint64_t)(zoff + grow * p.n + gcol + e), p.drop_p) ? x * keep_scale : 0.f;
+                    x = drop_keep(eff_seed(p, p.drop_seed), (uint64_t)(zoff + grow * p.n + gcol + e), p.drop_p) ? x * keep_scale : 0.f;
                 x += res[e];
                 if (G) x = gt[e] > 0.f ? x : 0.f;
                 if (p.beta != 0.f) x += p.beta * old[e];

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
         v = p.alpha * v + bias[i];
         if (p.relu) v = fmaxf(v, 0.f);
         if (p.drop_p > 0.f && erow >= p.drop_row0)
-            v = drop_keep(p.drop_seed, (uint64_t)(erow * p.n + ecol), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+            v = drop_keep(eff_seed(p, p.drop_seed), (uint64_t)(erow * p.n + ecol), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
         v += res[i];
         if (p.gate) v = gate[i] > 0.f ? v : 0.f;
         if (p.beta != 0.f) v += p.beta * cold[i];

@@ -318,6 +318,74 @@ def _colsum(x):
     return out
 
 
+
+class _SlabPool:
+    """Fixed homes for the slabs of a decode plan.
+
+    mssr_decode_fwd / _bwd replay a recorded hipGraph when a plan's CONTENTS repeat (include/mssr_hip.h), and the
+    contents are mostly buffer addresses.  torch's caching allocator returns the large slabs to the same place step
+    after step, but not the medium and small ones (measured: stats, nf, logits, src_mask, dX, d_e, dnf moved on every
+    step of the WGAN loop), so no plan ever matched.  The pool hands out the SAME tensor for the same (name, shape,
+    dtype, device, stream) whenever the previous holder has returned it: a ``lease`` collects what one decode call
+    took and gives everything back when it is dropped (end of the backward, or when autograd frees the node).
+    Two decodes in flight at once (both saved for backward) simply hold two different tensors of a kind.
+    Reuse is ordered by the stream (part of the key): the next holder's kernels are enqueued behind the previous
+    holder's.  MSSR_SLAB_POOL_GB (default 96) bounds what the pool keeps while idle; beyond it the free lists are
+    dropped (back to the allocator)."""
+
+    def __init__(self):
+        self.free = {}
+        self.held_bytes = 0
+        self.cap = int(float(os.environ.get("MSSR_SLAB_POOL_GB", "96")) * (1 << 30))
+
+    def lease(self, device):
+        return _Lease(self, device)
+
+    def clear(self):
+        self.free.clear()
+        self.held_bytes = 0
+
+
+class _Lease:
+    def __init__(self, pool, device):
+        self.pool, self.device, self.taken = pool, device, []
+        self.stream = torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0
+
+    def take(self, name, shape, dtype, zero=False):
+        key = (name, tuple(int(v) for v in shape), dtype, self.device, self.stream)
+        lst = self.pool.free.get(key)
+        if lst:
+            t = lst.pop()
+            self.pool.held_bytes -= t.numel() * t.element_size()
+        else:
+            t = torch.empty(key[1], dtype=dtype, device=self.device)
+        if zero:
+            t.zero_()
+        self.taken.append((key, t))
+        return t
+
+    def release(self):
+        pool, taken, self.taken = self.pool, self.taken, []
+        for key, t in taken:
+            pool.free.setdefault(key, []).append(t)
+            pool.held_bytes += t.numel() * t.element_size()
+        if pool.held_bytes > pool.cap:
+            pool.clear()
+
+    def __del__(self):
+        try:
+            self.release()
+        except Exception:           # interpreter shutdown
+            pass
+
+
+_slabs = _SlabPool()
+
+
+def clear_slab_pool():
+    _slabs.clear()
+
+
 def _make_plan(spec, mem, greedy=False):
     """Slabs + mssr_decode_plan for one decode over ``mem`` [B, Ls, d] (forward part).  ``greedy``: a forward-only
     plan that hands token ids from step to step -- no probability slab, one input slot (the one-hot <s>)."""
@@ -326,17 +394,21 @@ def _make_plan(spec, mem, greedy=False):
     B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
     L.require_cuda(mem)
     memc = ops.cast(mem).detach().contiguous().view(B * Ls, d)
+    lease = _slabs.lease(dev)           # every slab from its fixed home (recorded sweeps replay only on equal plans)
+    e = lambda name, *shape, dtype=cd, zero=False: lease.take(name, shape, dtype, zero)  # noqa: E731
     # context keys|values of the memory bank for every layer in one product: [B*Ls, NL*2d]
-    mem_kv = ops.gemm(memc, pk.w_ckv, True, cd, bias=pk.b_ckv)
+    mem_kv = ops.gemm(memc, pk.w_ckv, True, cd, bias=pk.b_ckv, out=e("mem_kv", B * Ls, pk.w_ckv.shape[0]))
     Ts = T if spec.save else 1
-    e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+    src_mask = e("src_mask", B, Ls, dtype=torch.uint8)
+    src_mask.copy_(spec.src_mask)
     bufs = dict(
-        mem=memc, mem_kv=mem_kv,
-        in_all=torch.zeros(1 if greedy else T + 1, B, Vp, dtype=cd, device=dev),
-        probs=e(1 if greedy else T, 1 if greedy else B, V, dtype=torch.float32),
-        X=e(NL + 1, Ts * B, d), qkv=e(NL, T * B, 3 * d), actD=e(NL, 8, Ts * B, d), actF=e(NL, Ts * B, ff),
-        stats=e(3 * NL + 1, 2, Ts * B, dtype=torch.float32), nf=e(Ts * B, d), logits=e(B, Vp), tmp=e(B, d),
-        ws=ops._workspace(dev))
+        lease=lease, mem=memc, mem_kv=mem_kv, src_mask=src_mask,
+        in_all=e("in_all", 1 if greedy else T + 1, B, Vp, zero=True),
+        # the probabilities leave with the caller: not pooled (large: the allocator keeps their place)
+        probs=torch.empty(1 if greedy else T, 1 if greedy else B, V, dtype=torch.float32, device=dev),
+        X=e("X", NL + 1, Ts * B, d), qkv=e("qkv", NL, T * B, 3 * d), actD=e("actD", NL, 8, Ts * B, d),
+        actF=e("actF", NL, Ts * B, ff), stats=e("stats", 3 * NL + 1, 2, Ts * B, dtype=torch.float32),
+        nf=e("nf", Ts * B, d), logits=e("logits", B, Vp), tmp=e("tmp", B, d), ws=ops._workspace(dev))
     bufs["in_all"][0, :, spec.bos] = 1
     forced = None if greedy else getattr(spec, "forced", None)
     if forced is not None:          # teacher-forced sentences [0, F): one-hot target words as the inputs of steps < Tf
@@ -344,7 +416,7 @@ def _make_plan(spec, mem, greedy=False):
         rows = bufs["in_all"][:Tf, :F]
         rows[0].zero_()
         rows.scatter_(2, forced.unsqueeze(-1), 1)
-        smask = torch.zeros(B, T, dtype=torch.uint8, device=dev)
+        smask = e("self_mask", B, T, dtype=torch.uint8, zero=True)
         smask[:F, :Tf] = forced.t().eq(spec.pad)
         bufs["self_mask"] = smask
     plan = L.DecodePlan()
@@ -363,7 +435,7 @@ def _make_plan(spec, mem, greedy=False):
             ("wg_gen", "cs_gen", "bf_gen") if pk.fuse_ln else ()):
         setattr(plan, name, getattr(pk, name).data_ptr())
     plan.pe = spec.pe.data_ptr()
-    plan.src_mask = spec.src_mask.data_ptr()
+    plan.src_mask = bufs["src_mask"].data_ptr()
     for name in ("mem_kv", "in_all", "probs", "X", "qkv", "actD", "actF", "stats", "nf", "logits", "tmp"):
         setattr(plan, name, bufs[name].data_ptr())
     plan.gemm_ws, plan.gemm_ws_bytes = bufs["ws"].data_ptr(), bufs["ws"].numel() * 4
@@ -440,12 +512,13 @@ class _SoftDecode(Function):
         B, Ls, T, NL, d, ff, V, Vp = spec.B, spec.Ls, spec.T, pk.NL, pk.d, pk.ff, pk.V, pk.Vp
         H = spec.heads
         R = T * B
-        z = lambda *shape, dtype=cd: torch.zeros(*shape, dtype=dtype, device=dev)  # noqa: E731
         e = lambda *shape, dtype=cd: torch.empty(*shape, dtype=dtype, device=dev)  # noqa: E731
+        lease = bufs["lease"]           # the gradient slabs join the forward's lease: fixed homes, returned together
+        pe = lambda name, *shape, dtype=cd, zero=False: lease.take(name, shape, dtype, zero)  # noqa: E731
         E0 = spec.eval_rows         # sentences [0, E0) ran in eval mode and carry no gradient: the sweep skips them
         # the sweep accumulates into dprobs in place (step s adds the input gradient of step s+1): a slab of its own
         groups = getattr(spec, "groups", None)
-        dprobs = e(T, B, V, dtype=torch.float32)
+        dprobs = pe("dprobs", T, B, V, dtype=torch.float32)
         if groups is None:
             dprobs[:, E0:].copy_(douts[0][:, E0:])
         else:
@@ -462,10 +535,11 @@ class _SoftDecode(Function):
                     dprobs[:te, b0:b1].copy_(dg)
                 seen.append((te, b0, b1))
         g = dict(dprobs=dprobs,
-                 dlogits=z(R, Vp), dX=e(2, B, d), dqkv=e(NL, R, 3 * d), dactD=e(NL, 7, R, d), dactF=e(NL, R, ff),
-                 dctx=e(NL, 2, R, d), ds_self=e(NL, 2, T, B * H, T, dtype=torch.float32),
-                 ds_ctx=e(NL, 2, T, B * H, Ls, dtype=torch.float32),
-                 d_e=e(R, d), dnf=e(R, d))
+                 dlogits=pe("dlogits", R, Vp, zero=True), dX=pe("dX", 2, B, d), dqkv=pe("dqkv", NL, R, 3 * d),
+                 dactD=pe("dactD", NL, 7, R, d), dactF=pe("dactF", NL, R, ff), dctx=pe("dctx", NL, 2, R, d),
+                 ds_self=pe("ds_self", NL, 2, T, B * H, T, dtype=torch.float32),
+                 ds_ctx=pe("ds_ctx", NL, 2, T, B * H, Ls, dtype=torch.float32),
+                 d_e=pe("d_e", R, d), dnf=pe("dnf", R, d))
         for name, t in g.items():
             setattr(plan, name, t.data_ptr())
         # sentences whose groups end before the sweep does carry no gradient at the later steps: when they are a

@@ -22,6 +22,29 @@ from .train_and_translate import dec_output_length, generator_probs
 from .utils.misc import sequence_mask
 
 
+_mode_lists = {}
+
+
+def set_mode(module, training):
+    """``module.train(training)`` without nn.Module's recursive walk: the phases flip the modes of all four networks
+    several times per step (onmt/trainer_wgan_wh.py:507-510, 866-869), and ``Module.train`` re-walks ~1 900 submodules
+    through ``__setattr__`` every time (7 ms of host time per WGAN step).  The submodule list is cached per network
+    (rebuilt when the module count changes) and ``training`` is written into each instance dict; nothing happens when
+    the root already has the requested mode."""
+    training = bool(training)
+    if module.training == training:
+        return module
+    key = id(module)
+    hit = _mode_lists.get(key)
+    if hit is None or hit[0]() is not module:
+        import weakref
+        mods = list(module.modules())
+        _mode_lists[key] = hit = (weakref.ref(module), mods)
+    for m in hit[1]:
+        m.__dict__["training"] = training
+    return module
+
+
 def cal_disc_loss(probs, labels):
     """probs[i, labels[i]] as a [N] tensor (one gather instead of the reference's per-row loop).  ``labels``:
     a device tensor (no host round trip) or a Python list as in the reference."""
@@ -267,10 +290,11 @@ class Trainer:
         """``_shared`` = (style representation, fake-text probabilities) computed by train_wgan_step in the sweep it
         shares with the generator phase; None: computed here, as the reference does (:530-535)."""
         cfg = self.cfg
-        self.style_generator.eval()
-        self.model.eval()
-        self.style_discriminator.train()
-        self.text_discriminator.train()
+        if _shared is None:                 # with the shared sweep the generator side does not run in this phase
+            set_mode(self.style_generator, False)
+            set_mode(self.model, False)
+        set_mode(self.style_discriminator, True)
+        set_mode(self.text_discriminator, True)
         self.style_discriminator_optim.zero_grad()
         self.text_discriminator_optim.zero_grad()
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
@@ -413,13 +437,13 @@ class Trainer:
         if 3 * B * real_src.size(0) > cfg.eval_rows_max_tokens:
             # long batches fill the chip with the training sentences alone: the eval-mode sentences would only add
             # their rows to the encoders' backward.  Encode them on their own (forward-only plans), share the decode.
-            self.style_generator.eval()
-            self.model.eval()
+            set_mode(self.style_generator, False)
+            set_mode(self.model, False)
             with torch.no_grad():
                 rep_d = self._gen_style_represents(labels, real_src, real_len)
                 _, mem_d, _ = self._encode(real_src, real_len, rep_d)
-            self.style_generator.train()
-            self.model.train()
+            set_mode(self.style_generator, True)
+            set_mode(self.model, True)
             rep_all = self._gen_style_represents(torch.cat([desired, desired, labels]), real_src.repeat(1, 3, 1), len3)
             rep, rep2, rep3 = rep_all[:, :B], rep_all[:, B:2 * B], rep_all[:, 2 * B:]
             _, mem, _ = self._encode(src3[:, B:], len3[B:], torch.cat([rep3, rep], 1))
@@ -486,8 +510,8 @@ class Trainer:
         # eval mode under no_grad (:530-535: own-style representation -> bonded encoder states -> decoded text) rides
         # along as the first B sentences of the same style-generator, encoder and decode calls (eval_rows: those
         # sentences skip every dropout site and receive no gradient)
-        self.style_generator.train()
-        self.model.train()
+        set_mode(self.style_generator, True)
+        set_mode(self.model, True)
         self.style_generator_optim.zero_grad()
         self.model_optim.zero_grad()
         rep2, probs, sprobs, fake, rep_d = self._generator_forward_batched(labels, real_src, real_len, tgt_len,
@@ -498,10 +522,10 @@ class Trainer:
 
     def train_generator(self, batch, _shared=None):
         cfg = self.cfg
-        self.style_generator.train()
-        self.model.train()
-        self.style_discriminator.eval()
-        self.text_discriminator.eval()
+        set_mode(self.style_generator, True)
+        set_mode(self.model, True)
+        set_mode(self.style_discriminator, False)
+        set_mode(self.text_discriminator, False)
         if _shared is None:
             self.style_generator_optim.zero_grad()
             self.model_optim.zero_grad()
@@ -602,8 +626,8 @@ class Trainer:
 
     def train_reconstruct(self, batch):
         cfg = self.cfg
-        self.style_generator.train()
-        self.model.train()
+        set_mode(self.style_generator, True)
+        set_mode(self.model, True)
         self.style_generator_optim.zero_grad()
         self.model_optim.zero_grad()
         if cfg.batch_generator_phase and cfg.use_cls_feedback and cfg.sr_noise_prob == 0:
@@ -654,8 +678,8 @@ class Trainer:
         return PhaseLog(names, vals, check=self._label_check())
 
     def init_launch(self, batch):
-        self.style_generator.train()
-        self.model.train()
+        set_mode(self.style_generator, True)
+        set_mode(self.model, True)
         self.style_generator_optim.zero_grad()
         self.model_optim.zero_grad()
         labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)

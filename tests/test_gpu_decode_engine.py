@@ -390,3 +390,46 @@ def test_row_groups_as_separate_outputs_fp32(ops, case):
     with torch.no_grad():
         fd = float((loss_of(mem + eps * direction) - loss_of(mem - eps * direction)) / (2 * eps))
     assert abs(fd - analytic) <= 1e-2 * max(abs(fd), 1e-3), (fd, analytic)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_recorded_sweeps_replay_bit_identically(ops, dtype, monkeypatch):
+    """mssr_decode_fwd / mssr_decode_bwd record a sweep as a hipGraph the second time the same plan arrives and replay
+    it afterwards (include/mssr_hip.h).  Same seed, same inputs, dropout on: the replayed calls must reproduce the
+    eager first call -- probabilities bit for bit (the recorded kernels read the seed from a device word instead of
+    their arguments: a wrong seed shows up as other dropout masks), gradients up to the float atomics of the
+    weight-gradient products -- and a call with ANOTHER seed through the same recording must differ."""
+    from mssrnet_style_transfer_amd import _lib as L
+    from mssrnet_style_transfer_amd.decode_engine import soft_decode
+    lib = L.load()
+    ops.set_compute_dtype(dtype)
+    cfg = MSSRConfig.small(dropout=0.1, attention_dropout=0.1)
+    B, Ls, steps = 6, 7, 9
+    model, src, lens, mem = setup(cfg, B, Ls, seed=3)
+    model.train()
+    model.decoder.init_state(src, None, None)
+    w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
+    seeds = iter([1234, 1234, 1234, 1234, 99, 1234])
+    monkeypatch.setattr(ops, "next_seed", lambda: next(seeds))
+    before = lib.mssr_decode_graphs()
+    outs = []
+    for _ in range(6):
+        model.zero_grad()
+        m = mem.clone().requires_grad_(True)
+        probs = soft_decode(model, cfg, m, lens, steps)
+        (probs * w).sum().backward()
+        g = torch.cat([p.grad.reshape(-1) for p in model.decoder.parameters() if p.grad is not None])
+        # results go to the host: device-side copies kept across iterations would change what the allocator hands out
+        outs.append((probs.detach().cpu(), m.grad.cpu(), g.cpu()))
+        del probs, m, g
+    recorded = lib.mssr_decode_graphs() - before
+    # buffers come from torch's caching allocator: the same sizes in the same order return the same blocks, so the
+    # plans of calls 2.. match call 1's and both directions were recorded
+    assert recorded >= 2, "no sweep was recorded (%d): the plans' buffers moved between identical calls" % recorded
+    p0, gm0, g0 = outs[0]                                    # eager
+    for i in (1, 2, 3, 5):                                   # recorded at call 2, replayed afterwards
+        p, gm, g = outs[i]
+        assert torch.equal(p, p0), "call %d: probabilities differ from the eager call" % (i + 1)
+        assert_close(gm, gm0, 1e-5, "d memory_bank, call %d" % (i + 1), floor=1e-7)
+        assert_close(g, g0, 1e-5, "decoder gradients, call %d" % (i + 1), floor=1e-7)
+    assert not torch.equal(outs[4][0], p0), "another seed through the same recording gave the same dropout masks"
