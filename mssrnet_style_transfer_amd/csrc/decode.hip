@@ -372,6 +372,9 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     load_chunk<T, AT_NL>(v0, vp, kv_ts, 0, r, RPL, Lk);
     const V qf = R::load(qp);
     const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
+    // dropout decision of key `lane` (index + seed only): taken under the loads
+    const uint32_t thr = drop_thr16(p_drop);
+    const bool keep0 = p_drop > 0.f ? keep16(seed, (uint64_t)bh * AT_MAXK + lane, thr) : true;
 
     auto scores = [&](const V (&kt)[AT_NL], int t0) {
 #pragma unroll
@@ -407,10 +410,9 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t thr = drop_thr16(p_drop);
     for (int t = lane; t < Lk; t += 64) {
         float p = s[t] * inv;
-        if (p_drop > 0.f) p = keep16(seed, (uint64_t)bh * AT_MAXK + t, thr) ? p * keep_scale : 0.f;
+        if (p_drop > 0.f) p = (t < 64 ? keep0 : keep16(seed, (uint64_t)bh * AT_MAXK + t, thr)) ? p * keep_scale : 0.f;
         s[t] = p;
     }
     wave_lds_sync();
@@ -478,6 +480,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     const V qf = R::load(qp);
     const V df = R::load(dcp);
     const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
+    const uint32_t thr = drop_thr16(p_drop);         // dropout decision of key `lane`: taken under the loads
+    const bool keep0 = p_drop > 0.f ? keep16(seed, (uint64_t)(bh + bh_off) * AT_MAXK + lane, thr) : true;
     float ck0 = 0.f, cv0 = 0.f;
     if (gather) {
         load_chunk<T, AT_NL>(q0, qp, q_ss, 0, r, RPL, n_rows);
@@ -528,12 +532,11 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     sum = wave_sum(sum);
     const float inv = 1.0f / sum;
     const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
-    const uint32_t thr = drop_thr16(p_drop);
     float rr = 0.f;
     for (int t = lane; t < Lk; t += 64) {
         const float p = s[t] * inv;
         float m = 1.0f;
-        if (p_drop > 0.f) m = keep16(seed, (uint64_t)(bh + bh_off) * AT_MAXK + t, thr) ? keep_scale : 0.f;
+        if (p_drop > 0.f) m = (t < 64 ? keep0 : keep16(seed, (uint64_t)(bh + bh_off) * AT_MAXK + t, thr)) ? keep_scale : 0.f;
         const float dp = dpv[t] * m;
         s[t] = p;
         dpv[t] = dp;

@@ -65,12 +65,14 @@ __device__ __forceinline__ int64_t seg_row(int64_t k, int64_t seg_len, int64_t s
 }
 
 // Issues the DMA of one operand tile.  ext = number of rows (KM) / columns (RM) of the operand, x0 = first of this tile.
-template <bool KM>
+// X = rows (KM) / columns (RM) of the tile: 128, or 64 for the small-tile KM form
+template <bool KM, int X = 128>
 __device__ __forceinline__ void pp_stage(const bf16* __restrict__ src, int64_t ld, int64_t x0, int64_t ext, int64_t k0,
                                          int64_t K, unsigned char* tile, int64_t seg_len, int64_t seg_stride) {
+    static_assert(KM || X == 128, "the k-major image is 128 columns wide");
     const int tid = threadIdx.x;
 #pragma unroll
-    for (int i = 0; i < PP_TILE_BYTES / 16 / PP_THREADS; ++i) {
+    for (int i = 0; i < X * PP_BK * 2 / 16 / PP_THREADS; ++i) {
         const int L = i * PP_THREADS + tid;          // 16-B slot of the image this lane fills
         const bf16* gp;
         if (KM) {
@@ -112,10 +114,16 @@ __device__ __forceinline__ bf16x8 pp_frag(const unsigned char* tile, int x0, int
     }
 }
 
-template <typename TO, bool A_KM, bool B_KM>
+// BM x BN: block tile.  128 x 128 everywhere but for the k-contiguous ("NT") products with few 128 x 128 tiles (the
+// encoders' projections at 3 840 - 5 440 rows: 120 - 170 tiles on 256 CUs, each CU waiting out every K-step's DMA round
+// trip alone): 64 x 64 tiles put four times as many blocks on the chip, several per CU, whose K-steps overlap.
+template <typename TO, bool A_KM, bool B_KM, int BM = 128, int BN = 128>
 __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs P) {
+    static_assert((BM == 128 && BN == 128) || (A_KM && B_KM), "small tiles: k-contiguous operands only");
+    constexpr int A_BYTES = BM * PP_BK * 2, B_BYTES = BN * PP_BK * 2, STAGE = A_BYTES + B_BYTES;
+    constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;      // a wave's sub-tile and its fragments
     // ONE shared array (a second LDS object makes hipcc drain the DMA queue before every fragment read)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[4 * PP_TILE_BYTES];
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
     const GemmArgs& p = P.g;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
     const int id = blockIdx.x, xcd = id & 7, q8 = nt >> 3, r8 = nt & 7;
     const int tile = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (id >> 3);
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
-    const int64_t m0 = (int64_t)tm * PP_BM, n0 = (int64_t)tn * PP_BN;
+    const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
     const int64_t zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
     const bf16* A = reinterpret_cast<const bf16*>(p.a) + zo * p.a_bo + zi * p.a_bi;
@@ -137,42 +145,42 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
     const int64_t t_begin = (int64_t)blockIdx.y * per;
     const int64_t t_end = t_begin + per < nk_all ? t_begin + per : nk_all;
 
-    f32x4 acc[4][4];
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // RM operands are fetched in 8-column chunks: a ragged width reads on into the row's padding (ld >= width rounded up)
     const int64_t a_ext = A_KM ? p.m : (p.m + 7) & ~(int64_t)7, b_ext = B_KM ? p.n : (p.n + 7) & ~(int64_t)7;
     if (t_begin < t_end) {
-        pp_stage<A_KM>(A, P.a_ld, m0, a_ext, t_begin * PP_BK, p.k, smem, P.seg_len, P.seg_stride);
-        pp_stage<B_KM>(B, P.b_ld, n0, b_ext, t_begin * PP_BK, p.k, smem + PP_TILE_BYTES, P.seg_len, P.seg_stride);
+        pp_stage<A_KM, BM>(A, P.a_ld, m0, a_ext, t_begin * PP_BK, p.k, smem, P.seg_len, P.seg_stride);
+        pp_stage<B_KM, BN>(B, P.b_ld, n0, b_ext, t_begin * PP_BK, p.k, smem + A_BYTES, P.seg_len, P.seg_stride);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
     for (int64_t t = t_begin; t < t_end; ++t) {
         const int cur = (int)((t - t_begin) & 1);
-        const unsigned char* At = smem + cur * 2 * PP_TILE_BYTES;
-        const unsigned char* Bt = At + PP_TILE_BYTES;
+        const unsigned char* At = smem + cur * STAGE;
+        const unsigned char* Bt = At + A_BYTES;
         if (t + 1 < t_end) {
-            unsigned char* An = smem + (cur ^ 1) * 2 * PP_TILE_BYTES;
-            pp_stage<A_KM>(A, P.a_ld, m0, a_ext, (t + 1) * PP_BK, p.k, An, P.seg_len, P.seg_stride);
-            pp_stage<B_KM>(B, P.b_ld, n0, b_ext, (t + 1) * PP_BK, p.k, An + PP_TILE_BYTES, P.seg_len, P.seg_stride);
+            unsigned char* An = smem + (cur ^ 1) * STAGE;
+            pp_stage<A_KM, BM>(A, P.a_ld, m0, a_ext, (t + 1) * PP_BK, p.k, An, P.seg_len, P.seg_stride);
+            pp_stage<B_KM, BN>(B, P.b_ld, n0, b_ext, (t + 1) * PP_BK, p.k, An + A_BYTES, P.seg_len, P.seg_stride);
         }
         const int ksteps = (p.k - t * PP_BK) >= PP_BK ? 2 : 1;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             if (kk < ksteps) {
-                bf16x8 fa[4], fb[4];
+                bf16x8 fa[FM], fb[FN];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[i] = pp_frag<A_KM>(At, wm * 64 + i * 16, kk, lane);
+                for (int i = 0; i < FM; ++i) fa[i] = pp_frag<A_KM>(At, wm * WM + i * 16, kk, lane);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) fb[j] = pp_frag<B_KM>(Bt, wn * 64 + j * 16, kk, lane);
+                for (int j = 0; j < FN; ++j) fb[j] = pp_frag<B_KM>(Bt, wn * WN + j * 16, kk, lane);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
+                    for (int j = 0; j < FN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
             }
         }
@@ -184,18 +192,21 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
     // 16 KB of the now idle LDS as a [64][64] fp32 image (16-column groups XOR-swizzled by the row quad, so the four
     // row groups of one store instruction hit different banks) and come back as whole rows: every lane finishes 16
     // bytes of one output row, with its bias / residual / gate / C operands fetched as 16-byte vectors too.
-    float* Wt = reinterpret_cast<float*>(smem) + wave * 4096;
+    // (a wave's [WM][WN] fp32 image: WM * WN * 4 bytes x 4 waves = BM * BN * 4 <= 2 * STAGE for both tile shapes)
+    static_assert(BM * BN * 4 <= 2 * STAGE, "epilogue image does not fit the staging buffers");
+    float* Wt = reinterpret_cast<float*>(smem) + wave * (WM * WN);
+    constexpr int SWZ = FN - 1;                   // 16-column groups of a row, minus one (a power of two)
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = i * 16 + (lane >> 4) * 4 + r, col = j * 16 + (lane & 15);
-                Wt[row * 64 + (col ^ (((row >> 2) & 3) << 4))] = acc[i][j][r];
+                Wt[row * WN + (col ^ (((row >> 2) & SWZ) << 4))] = acc[i][j][r];
             }
     constexpr int V = 16 / (int)sizeof(TO);      // output elements per lane and instruction: 8 (bf16) or 4 (fp32)
-    constexpr int LPR = 64 / V, RPI = 64 / LPR;
+    constexpr int LPR = WN / V, RPI = 64 / LPR;
     const int64_t coff = zo * p.c_bo + zi * p.c_bi;
     TO* C = reinterpret_cast<TO*>(p.c) + coff;
     const bf16* R = p.residual ? reinterpret_cast<const bf16*>(p.residual) + coff : nullptr;
@@ -204,7 +215,7 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
     const float keep_scale = 1.0f / (1.0f - p.drop_p);
     if (P.ksplit > 1) {
         // K slices: one 256-byte row segment per wave instruction (the shape the memory-side fp32 atomics run at full rate)
-        if constexpr (sizeof(TO) == 4) {
+        if constexpr (sizeof(TO) == 4 && BM == 128 && BN == 128) {
             const int64_t gcol = n0 + wn * 64 + lane;
             if (gcol < p.n) {
 #pragma unroll 8
@@ -219,12 +230,12 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
         return;
     }
 #pragma unroll 4
-    for (int it = 0; it < 64 / RPI; ++it) {
+    for (int it = 0; it < WM / RPI; ++it) {
         const int row = it * RPI + lane / LPR, c = (lane % LPR) * V;
-        const int64_t grow = m0 + wm * 64 + row, gcol = n0 + wn * 64 + c;
+        const int64_t grow = m0 + wm * WM + row, gcol = n0 + wn * WN + c;
         if (grow >= p.m || gcol >= p.n) continue;
         float v[V];
-        const float* src = Wt + row * 64 + (c ^ (((row >> 2) & 3) << 4));
+        const float* src = Wt + row * WN + (c ^ (((row >> 2) & SWZ) << 4));
 #pragma unroll
         for (int e = 0; e < V; e += 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(src + e);
@@ -290,8 +301,9 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
 }
 
 template <typename TO>
-static void pipe_launch(const PipeArgs& P, bool a_km, bool b_km, dim3 grid, hipStream_t s) {
-    if (a_km && b_km) klaunch(gemm_pipe_kernel<TO, true, true>, grid, dim3(PP_THREADS), 0, s, P);
+static void pipe_launch(const PipeArgs& P, bool a_km, bool b_km, dim3 grid, hipStream_t s, bool small_tiles) {
+    if (small_tiles) klaunch(gemm_pipe_kernel<TO, true, true, 64, 64>, grid, dim3(PP_THREADS), 0, s, P);
+    else if (a_km && b_km) klaunch(gemm_pipe_kernel<TO, true, true>, grid, dim3(PP_THREADS), 0, s, P);
     else if (a_km) klaunch(gemm_pipe_kernel<TO, true, false>, grid, dim3(PP_THREADS), 0, s, P);
     else klaunch(gemm_pipe_kernel<TO, false, false>, grid, dim3(PP_THREADS), 0, s, P);
 }
@@ -383,9 +395,22 @@ bool gemm_pipe_try(const GemmArgs& g, int in_dtype, int out_dtype, int64_t batch
     if (!pipe_plan(g, in_dtype, out_dtype, batch, P, a_km, b_km)) return false;
     if (!a_km && P.ksplit > 1 && g.beta == 0.f &&
         hipMemsetAsync(g.c, 0, sizeof(float) * (size_t)(g.m * g.n * batch), s) != hipSuccess) return false;
+    // few 128 x 128 tiles (under one per CU): 64 x 64 tiles, several blocks per CU (see the kernel's comment)
+    static const int64_t small_below = [] {
+        const char* e = getenv("MSSR_PIPE_SMALL_BELOW");
+        // tools/pipe_mid_bench.py, 128 x 128 -> 64 x 64 tiles: 3840 x 512 x 512 (120 tiles) 13.1 -> 8.3 us, x 1024 (K)
+        // 18.1 -> 11.7, 3840 x 1024 x 512 (240) 14.2 -> 12.1, 3840 x 1536 x 512 (360) 17.8 -> 16.6; 32768 x 512 x 512
+        // (1024 tiles) 33.2 -> 37.7: the small tiles lose once the big ones fill the chip twice over
+        return e ? (int64_t)atoll(e) : (int64_t)400;
+    }();
+    const bool small = a_km && b_km && (int64_t)P.tiles_m * P.tiles_n * batch < small_below;
+    if (small) {
+        P.tiles_m = (int)((g.m + 63) / 64);
+        P.tiles_n = (int)((g.n + 63) / 64);
+    }
     const dim3 grid((unsigned)(P.tiles_m * P.tiles_n), (unsigned)P.ksplit, (unsigned)batch);
-    if (out_dtype == MSSR_F32) pipe_launch<float>(P, a_km, b_km, grid, s);
-    else pipe_launch<bf16>(P, a_km, b_km, grid, s);
+    if (out_dtype == MSSR_F32) pipe_launch<float>(P, a_km, b_km, grid, s, small);
+    else pipe_launch<bf16>(P, a_km, b_km, grid, s, small);
     return true;
 }
 

@@ -29,16 +29,18 @@ constexpr int SK_THREADS = 256;
 constexpr int SK_MAX_STEPS = 64;     // k-steps per block without split-K (K <= 2048)
 constexpr int SK_MAX_M = 8192;       // above this the general LDS-tiled kernel (operand reuse) takes over
 
-// F = fragments per tile edge: F = 1 -> 16x16 tile (M <= 128), F = 2 -> 32x32 tile (larger M)
-template <typename TO, bool LN, int F, int SK_GROUP>
+// FM x FN fragments per tile: 1 x 1 -> 16x16 tile (few rows), 2 x 2 -> 32x32 tile (larger M), 1 x 2 -> 16 rows x 32
+// columns (long-K decode products: a wave's A fragment feeds two column fragments, 25 % fewer bytes through the CU's
+// load path than two 16x16 tiles, and half as many blocks: one round on the chip)
+template <typename TO, bool LN, int FM, int FN, int SK_GROUP>
 __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs p) {
-    constexpr int TS = 16 * F;                 // tile edge
-    constexpr int TE = TS * TS;                // tile elements
-    constexpr int EPT = TE / SK_THREADS;       // epilogue elements per thread (1 or 4)
+    constexpr int TSM = 16 * FM, TSN = 16 * FN;    // tile rows, columns
+    constexpr int TE = TSM * TSN;                  // tile elements
+    constexpr int EPT = TE / SK_THREADS;           // epilogue elements per thread (1, 2 or 4)
     __shared__ __attribute__((aligned(16))) float red[4 * TE];
-    __shared__ float stat[4][TS][2];
+    __shared__ float stat[4][TSM][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int64_t n0 = (int64_t)blockIdx.x * TS, m0 = (int64_t)blockIdx.y * TS;
+    const int64_t n0 = (int64_t)blockIdx.x * TSN, m0 = (int64_t)blockIdx.y * TSM;
     const int split = blockIdx.z;
     const int64_t steps_total = p.k / 32;
     const int64_t per = (steps_total + p.ksplit - 1) / p.ksplit;
@@ -48,26 +50,33 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     const bf16* A = reinterpret_cast<const bf16*>(p.a);
     const bf16* W = reinterpret_cast<const bf16*>(p.b);
     const int koff = 8 * (lane >> 4);
-    int64_t arow[F], wrow[F];
+    int64_t arow[FM], wrow[FN];
 #pragma unroll
-    for (int f = 0; f < F; ++f) {
-        const int64_t ar = m0 + f * 16 + (lane & 15), wn = n0 + f * 16 + (lane & 15);
+    for (int f = 0; f < FM; ++f) {
+        const int64_t ar = m0 + f * 16 + (lane & 15);
         arow[f] = (ar < p.m ? ar : p.m - 1) * p.a_rs;
+    }
+#pragma unroll
+    for (int f = 0; f < FN; ++f) {
+        const int64_t wn = n0 + f * 16 + (lane & 15);
         wrow[f] = (wn < p.n ? wn : p.n - 1) * p.b_cs;            // B viewed [k,n]: n stride = b_cs
     }
 
-    // the elements this thread finishes (tile-local index e = threadIdx.x + i*256: row e / TS, col e % TS),
+    // the elements this thread finishes (tile-local index e = threadIdx.x + i*256: row e / TSN, col e % TSN),
     // and their epilogue operands, issued before the main loads
     float bias[EPT], res[EPT], gate[EPT], cold[EPT], lns[EPT];
-    bool eok[EPT];
+    bool eok[EPT], keepm[EPT];      // keepm: the element's dropout decision (index + seed only), taken under the loads
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = threadIdx.x + i * SK_THREADS;
-        const int64_t erow = m0 + e / TS, ecol = n0 + e % TS;
+        const int64_t erow = m0 + e / TSN, ecol = n0 + e % TSN;
         eok[i] = erow < p.m && ecol < p.n;
         bias[i] = res[i] = cold[i] = lns[i] = 0.f;
         gate[i] = 1.f;
+        keepm[i] = true;
         if (eok[i] && p.ksplit == 1) {
+            if (p.drop_p > 0.f && erow >= p.drop_row0)
+                keepm[i] = drop_keep(eff_seed(p, p.drop_seed), (uint64_t)(erow * p.n + ecol), p.drop_p);
             if (p.bias) bias[i] = p.bias[ecol];
             if (p.residual) res[i] = to_f(reinterpret_cast<const bf16*>(p.residual)[erow * p.ldr + ecol]);
             if (p.gate) gate[i] = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol]);
@@ -76,18 +85,18 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
         }
     }
 
-    f32x4 acc[F][F];
+    f32x4 acc[FM][FN];
 #pragma unroll
-    for (int i = 0; i < F; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float sx[F], sxx[F];
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx[FM], sxx[FM];
 #pragma unroll
-    for (int f = 0; f < F; ++f) sx[f] = sxx[f] = 0.f;
+    for (int f = 0; f < FM; ++f) sx[f] = sxx[f] = 0.f;
     // wave w owns k-steps s_begin + w, + 4, + 8 ... ; SK_GROUP of them in flight at a time  (contiguous quarters per
     // wave, so that one wave requests both halves of a 128-byte line back to back: WGAN step 51.0-51.6 ms against 50.8)
     for (int64_t s0 = s_begin + wave; s0 < s_end; s0 += 4 * SK_GROUP) {
-        bf16x8 fa[SK_GROUP][F], fb[SK_GROUP][F];
+        bf16x8 fa[SK_GROUP][FM], fb[SK_GROUP][FN];
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
             // unconditional loads (clamped to the last valid k-step): a branch around a load makes
@@ -96,10 +105,9 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             s = s < s_end ? s : s_end - 1;
             const int64_t k = s * 32 + koff;
 #pragma unroll
-            for (int f = 0; f < F; ++f) {
-                fb[g][f] = *reinterpret_cast<const bf16x8*>(W + wrow[f] + k);
-                fa[g][f] = *reinterpret_cast<const bf16x8*>(A + arow[f] + k);
-            }
+            for (int f = 0; f < FN; ++f) fb[g][f] = *reinterpret_cast<const bf16x8*>(W + wrow[f] + k);
+#pragma unroll
+            for (int f = 0; f < FM; ++f) fa[g][f] = *reinterpret_cast<const bf16x8*>(A + arow[f] + k);
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the whole batch of loads ahead of the first MFMA
 #pragma unroll
@@ -109,17 +117,17 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             const bool live = s0 + 4 * g < s_end;
             const unsigned msk = live ? 0xffffffffu : 0u;
 #pragma unroll
-            for (int j = 0; j < F; ++j) {
+            for (int j = 0; j < FN; ++j) {
                 u32x4 wb = __builtin_bit_cast(u32x4, fb[g][j]);
                 wb &= msk;
                 const bf16x8 fbm = __builtin_bit_cast(bf16x8, wb);
 #pragma unroll
-                for (int i = 0; i < F; ++i)
+                for (int i = 0; i < FM; ++i)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[g][i], fbm, acc[i][j], 0, 0, 0);
             }
             if (LN && live) {
 #pragma unroll
-                for (int f = 0; f < F; ++f)
+                for (int f = 0; f < FM; ++f)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float x = (float)fa[g][f][j];
@@ -129,17 +137,17 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             }
         }
     }
-    // partial tiles -> LDS as [wave][row*TS + col]  (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
+    // partial tiles -> LDS as [wave][row*TSN + col]  (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
 #pragma unroll
-    for (int i = 0; i < F; ++i)
+    for (int i = 0; i < FM; ++i)
 #pragma unroll
-        for (int j = 0; j < F; ++j)
+        for (int j = 0; j < FN; ++j)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                red[wave * TE + (i * 16 + (lane >> 4) * 4 + r) * TS + j * 16 + (lane & 15)] = acc[i][j][r];
+                red[wave * TE + (i * 16 + (lane >> 4) * 4 + r) * TSN + j * 16 + (lane & 15)] = acc[i][j][r];
     if (LN) {       // row sums: the 4 lanes (lane & 15, lane >> 4 = 0..3) of a wave hold one row's k-chunks
 #pragma unroll
-        for (int f = 0; f < F; ++f) {
+        for (int f = 0; f < FM; ++f) {
             sx[f] += __shfl_xor(sx[f], 16, 64);
             sx[f] += __shfl_xor(sx[f], 32, 64);
             sxx[f] += __shfl_xor(sxx[f], 16, 64);
@@ -155,8 +163,8 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     for (int i = 0; i < EPT; ++i) {
         if (!eok[i]) continue;
         const int e = threadIdx.x + i * SK_THREADS;
-        const int rl = e / TS;
-        const int64_t erow = m0 + rl, ecol = n0 + e % TS;
+        const int rl = e / TSN;
+        const int64_t erow = m0 + rl, ecol = n0 + e % TSN;
         float v = (red[e] + red[TE + e]) + (red[2 * TE + e] + red[3 * TE + e]);
         if (p.ksplit > 1) {
             p.partial[((int64_t)split * p.m + erow) * p.n + ecol] = v;
@@ -169,15 +177,14 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             const float var = fmaxf(s2 / (float)p.k - mean * mean, 0.f);
             const float rstd = rsqrtf(var + p.ln_eps);
             v = rstd * (v - mean * lns[i]);
-            if (blockIdx.x == 0 && (e % TS) == 0) {
+            if (blockIdx.x == 0 && (e % TSN) == 0) {
                 if (p.ln_mean) p.ln_mean[erow] = mean;
                 if (p.ln_rstd) p.ln_rstd[erow] = rstd;
             }
         }
         v = p.alpha * v + bias[i];
         if (p.relu) v = fmaxf(v, 0.f);
-        if (p.drop_p > 0.f && erow >= p.drop_row0)
-            v = drop_keep(eff_seed(p, p.drop_seed), (uint64_t)(erow * p.n + ecol), p.drop_p) ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
+        if (p.drop_p > 0.f && erow >= p.drop_row0) v = keepm[i] ? v * (1.0f / (1.0f - p.drop_p)) : 0.f;
         v += res[i];
         if (p.gate) v = gate[i] > 0.f ? v : 0.f;
         if (p.beta != 0.f) v += p.beta * cold[i];
@@ -302,11 +309,11 @@ static int skinny_group(const GemmArgs& a, int tile) {
     return per_wave <= 4 ? 4 : per_wave <= 8 ? 8 : per_wave <= 12 ? 12 : 4;
 }
 
-template <typename TO, bool LN, int F>
+template <typename TO, bool LN, int FN>
 static void skinny_launch_g(const GemmArgs& a, const dim3 grid, int group, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
-    if (group == 8) klaunch_events(gemm_skinny_kernel<TO, LN, F, 8>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
-    else if (group == 12) klaunch_events(gemm_skinny_kernel<TO, LN, F, 12>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
-    else klaunch_events(gemm_skinny_kernel<TO, LN, F, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    if (group == 8) klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 8>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    else if (group == 12) klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 12>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
+    else klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
 }
 
 template <typename TO>
@@ -316,15 +323,23 @@ static void skinny_launch(const GemmArgs& a, hipStream_t s) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     (void)prof_take(&e0, &e1);
     hipEvent_t e1_main = a.ksplit > 1 ? nullptr : e1;
-    if (tile == 16) {
+    // 16 x 32 tiles for the long-K products without a LayerNorm prologue (see the kernel's header comment)
+    static const int64_t wide_min_k = [] {
+        const char* e = getenv("MSSR_SKINNY_16X32_MINK");
+        return e ? (int64_t)atoll(e) : (int64_t)1024;
+    }();
+    if (tile == 16 && !a.ln_colsum && a.ksplit == 1 && a.k >= wide_min_k && a.n % 32 == 0 && a.m >= 64) {
+        const dim3 grid((unsigned)(a.n / 32), (unsigned)((a.m + 15) / 16), 1);
+        skinny_launch_g<TO, false, 2>(a, grid, skinny_group(a, tile), s, e0, e1_main);
+    } else if (tile == 16) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
         const int g = skinny_group(a, tile);
         if (a.ln_colsum) skinny_launch_g<TO, true, 1>(a, grid, g, s, e0, e1_main);
         else skinny_launch_g<TO, false, 1>(a, grid, g, s, e0, e1_main);
     } else {
         const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
-        if (a.ln_colsum) klaunch_events(gemm_skinny_kernel<TO, true, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
-        else klaunch_events(gemm_skinny_kernel<TO, false, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+        if (a.ln_colsum) klaunch_events(gemm_skinny_kernel<TO, true, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+        else klaunch_events(gemm_skinny_kernel<TO, false, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
     }
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;

@@ -381,6 +381,19 @@ class _Lease:
 
 _slabs = _SlabPool()
 
+# tools/sweep_bench.py: (kind, start event, end event) around every sweep call while a list is installed here
+sweep_events = None
+
+
+def _timed_sweep(kind, fn, plan):
+    if sweep_events is None:
+        return L.check(fn(ctypes.byref(plan), L.stream()), kind)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(fn(ctypes.byref(plan), L.stream()), kind)
+    e1.record()
+    sweep_events.append((kind, e0, e1))
+
 
 def clear_slab_pool():
     _slabs.clear()
@@ -480,7 +493,7 @@ class _SoftDecode(Function):
                     t = bufs[name]
                     t.view(-1, T, B, t.shape[-1])[:, late_step:, :late_row0].zero_()
                 bufs["stats"].view(-1, T, B)[:, late_step:, :late_row0].zero_()
-        L.check(lib.mssr_decode_fwd(ctypes.byref(plan), L.stream()), "decode_fwd")
+        _timed_sweep("decode_fwd", lib.mssr_decode_fwd, plan)
         probs = bufs.pop("probs")
         if spec.save:
             ctx.spec, ctx.plan, ctx.bufs = spec, plan, bufs
@@ -558,7 +571,7 @@ class _SoftDecode(Function):
             for name in ("dqkv", "dactD", "dactF", "d_e", "dnf"):
                 t = g[name]
                 t.view(-1, T, B, t.shape[-1])[:, :, :E0].zero_()
-        L.check(lib.mssr_decode_bwd(ctypes.byref(plan), L.stream()), "decode_bwd")
+        _timed_sweep("decode_bwd", lib.mssr_decode_bwd, plan)
 
         actD, actF, dactD, dactF, dqkv, X = bufs["actD"], bufs["actF"], g["dactD"], g["dactF"], g["dqkv"], bufs["X"]
         stats = bufs["stats"]
