@@ -145,6 +145,10 @@ int mssr_gemm_tile(int64_t m, int64_t n, int64_t batch);
  * per 16x16 (m <= 128) or 32x32 output tile, its four waves splitting K and loading straight into
  * MFMA fragments -- a single memory round trip per launch.  No reference counterpart. */
 int mssr_gemm_is_skinny(const mssr_gemm_desc* desc);
+/* Diagnostics (tools/stamp_bench.py), no reference counterpart: while `buf` (device memory, 8 x uint64 per thread block
+ * of the launches that follow) is set, the K-split kernel's blocks record the 100 MHz real-time clock at six points
+ * (start, loads issued, loads landed -- this adds a full wait --, tile in LDS, after the barrier, end).  NULL: off. */
+void mssr_debug_stamps(void* buf);
 
 /* Launch timing for the benchmark's roofline (no reference counterpart): between mssr_prof_start
  * and mssr_prof_stop every mssr_gemm launch -- direct or from inside the decode engine -- is timed with a HIP
@@ -453,7 +457,7 @@ typedef struct {
     void* in_all;                 /* [T+1][B, Vp] step inputs; slot 0 = one-hot <s>; padded columns zero */
     float* probs;                 /* [T][B, V] output probabilities (float) */
     void* X;                      /* [n_layers+1][Ts][B, d]   (Ts = save ? T : 1) */
-    void* qkv;                    /* [n_layers][T][B, 3d]     self-attention projections = K/V cache */
+    void* qkv;                    /* [n_layers][B][T, 3d]     self-attention projections = K/V cache (sentence-major) */
     void* actD;                   /* [n_layers][8][Ts][B, d]  n1|ctx1|h1|n2|qc|ctx2|h2|n3 */
     void* actF;                   /* [n_layers][Ts][B, ff] */
     float* stats;                 /* [3*n_layers+1][2][Ts][B] LayerNorm mean, rstd */

@@ -7,7 +7,9 @@
 // the layer_cache protocol of onmt/modules/multi_headed_attn.py:133-160 -> generator Linear +
 // softmax, :95-116).  All per-step tensors live in step-major slabs [T][B, width] that the
 // caller allocates once (mssr_decode_plan); the K/V "cache" is the packed projection slab
-// qkv[l] = [T][B, 3d] itself, so nothing is concatenated or copied as the sequence grows.
+// qkv[l] = [B][T, 3d] itself (sentence-major: a sentence's keys of all steps lie 3d apart, in one run of memory -- the
+// step attention walks them every step, and a step-major slab put every key 2 MB and more from the next at the
+// 128-word stress shape), so nothing is concatenated or copied as the sequence grows.
 // Weight / bias / LayerNorm gradients are NOT formed per step: the backward stores the
 // gradient of every GEMM output in a slab and the caller contracts each slab once at the end
 // (dW = dY_all^T X_all with a long reduction dimension instead of 28 products of depth 80).
@@ -977,7 +979,7 @@ static int check_plan(const mssr_decode_plan* p, int step, const char* who) {
 
 // Slab geometry (elements), shared by forward and backward.  Ts = save ? T : 1, slot = save ? step : 0.
 //   X     [n_layers+1][Ts][B,d]      residual stream entering layer l (l = n_layers: decoder output)
-//   qkv   [n_layers][T][B,3d]        packed self-attention projections = the K/V cache
+//   qkv   [n_layers][B][T,3d]        packed self-attention projections = the K/V cache (sentence-major)
 //   actD  [n_layers][8][Ts][B,d]     n1 | ctx1 | h1 | n2 | qc | ctx2 | h2 | n3
 //   actF  [n_layers][Ts][B,ff]       FFN inner activation (after ReLU and dropout)
 //   stats [3*n_layers+1][2][Ts][B]   LayerNorm mean, rstd (float)
@@ -1002,7 +1004,9 @@ struct Geo {
     char* act(int l, int kind) const { return rows(p->actD, ((int64_t)l * K_NKINDS + kind) * Ts + slot, d); }
     char* inter(int l) const { return rows(p->actF, (int64_t)l * Ts + slot, ff); }
     float* stat(int idx, int which) const { return p->stats + (((int64_t)idx * 2 + which) * Ts + slot) * B + r0; }
-    char* qkv(int l, int step) const { return rows(p->qkv, (int64_t)l * T + step, 3 * d); }
+    // row of sentence r0 at `step`; sentences are qkv_bs() elements apart, steps 3d
+    char* qkv(int l, int step) const { return at(p->qkv, (((int64_t)l * B + r0) * T + step) * 3 * d, es); }
+    int64_t qkv_bs() const { return (int64_t)T * 3 * d; }
     char* dact(int l, int kind, int step) const { return rows(p->dactD, ((int64_t)l * G_NKINDS + kind) * T + step, d); }
     char* dinter(int l, int step) const { return rows(p->dactF, (int64_t)l * T + step, ff); }
     char* dqkv(int l, int step) const { return rows(p->dqkv, (int64_t)l * T + step, 3 * d); }
@@ -1066,19 +1070,19 @@ static int step_fwd(const Ctx& c, int step) {
         char* qkv_s = G.qkv(l, step);
         // --- self attention block
         if (fuse) {     // LayerNorm folded into the projection (stats written by the GEMM, n1 not materialised)
-            if ((rc = gemm_nt(c, x, d, L.wg_qkv, d, qkv_s, 3 * d, R, 3 * d, d, L.bf_qkv, 0, nullptr, 0, nullptr, 0, 1.f,
+            if ((rc = gemm_nt(c, x, d, L.wg_qkv, d, qkv_s, G.qkv_bs(), R, 3 * d, d, L.bf_qkv, 0, nullptr, 0, nullptr, 0, 1.f,
                               0.f, c.dt, 0.f, 0, L.cs_qkv, G.stat(l * 3 + 0, 0), G.stat(l * 3 + 0, 1))))
                 return rc;
         } else {
             if ((rc = mssr_layernorm_fwd(x, L.ln1_g, L.ln1_b, n1, G.stat(l * 3 + 0, 0), G.stat(l * 3 + 0, 1), R, d,
                                          1e-6f, c.dt, c.s)))
                 return rc;
-            if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, 3 * d, R, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f,
+            if ((rc = gemm_nt(c, n1, d, L.w_qkv, d, qkv_s, G.qkv_bs(), R, 3 * d, d, L.b_qkv, 0, nullptr, 0, nullptr, 0, 1.f,
                               0.f, c.dt, 0.f, 0)))
                 return rc;
         }
-        DT_CALL(c, launch_attn_fwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
-                (int64_t)B * 3 * d, G.self_mask(), p->T, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
+        DT_CALL(c, launch_attn_fwd, c, qkv_s, G.qkv_bs(), qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, G.qkv_bs(),
+                (int64_t)3 * d, G.self_mask(), p->T, ctx1, d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, ctx1, d, L.w_so, d, h1, d, R, d, d, L.b_so, 0, x, d, nullptr, 0, 1.f, 0.f, c.dt, pd,
                           site_seed(c, step, l, 2), nullptr, nullptr, nullptr, c.eval_rows)))
             return rc;
@@ -1282,9 +1286,9 @@ static int step_bwd(const Ctx& c, int step) {
         if ((rc = ln_gemm(dn2, h1, L.ln2_g, l * 3 + 1, false, d_so, site_seed(c, step, l, 2), L.wt_so, d, dctx1, d, nullptr,
                           0, 1.f)))
             return rc;
-        DT_CALL(c, launch_attn_bwd, c, qkv_s, 3 * d, qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, 3 * d,
-                (int64_t)B * 3 * d, G.self_mask(), p->T, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
-                p->T, 1, step, (int64_t)B * p->heads * p->T, (int64_t)B * 3 * d, (int64_t)B * d,
+        DT_CALL(c, launch_attn_bwd, c, qkv_s, G.qkv_bs(), qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, G.qkv_bs(),
+                (int64_t)3 * d, G.self_mask(), p->T, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
+                p->T, 1, step, (int64_t)B * p->heads * p->T, (int64_t)3 * d, (int64_t)B * d,
                 dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))

@@ -242,6 +242,8 @@ static void launch(const GemmArgs& a0, int64_t batch0, hipStream_t s) {
 }  // namespace mssr
 
 thread_local const uint64_t* mssr::tl_seed_base = nullptr;
+uint64_t* mssr::g_dbg_stamps = nullptr;
+extern "C" void mssr_debug_stamps(void* buf) { mssr::g_dbg_stamps = (uint64_t*)buf; }
 
 using namespace mssr;
 
@@ -259,6 +261,7 @@ void mssr::gemm_fill_args(const mssr_gemm_desc* d, GemmArgs& a) {
     a.alpha = d->alpha; a.beta = d->beta; a.relu = d->relu;
     a.drop_p = d->drop_p; a.drop_seed = d->drop_seed; a.drop_row0 = d->drop_row0;
     a.seed_base = tl_seed_base;
+    a.dbg_stamps = g_dbg_stamps;
     a.k_seg_len = d->k_seg_len; a.k_seg_stride = d->k_seg_stride;
     a.ksplit = 1;
     a.partial = nullptr;

@@ -24,6 +24,7 @@ struct GemmArgs {
     // is replayed as a hipGraph keeps the per-call seed there, so the captured kernel arguments never change
     // (decode.hip: the by-value seeds then hold the site offsets only).
     const uint64_t* seed_base;
+    uint64_t* dbg_stamps;   // diagnostics (tools/stamp_bench.py, MSSR_GEMM_STAMPS): [block][8] s_memtime stamps; null otherwise
     int64_t drop_row0;  // rows below this one are NOT dropped (and not rescaled): eval-mode rows sharing a launch
     int64_t k_seg_len, k_seg_stride;    // segmented reduction index (weight-gradient kernel only), 0 = plain
     float* partial;     // skinny split-K: fp32 slabs [ksplit][m][n]
@@ -57,6 +58,19 @@ __device__ __forceinline__ uint64_t eff_seed(const GemmArgs& p, uint64_t s) { re
 // the seed_base every GemmArgs filled on this thread receives (gemm_fill_args); set by the decode engine while it
 // records a sweep, null otherwise
 extern thread_local const uint64_t* tl_seed_base;
+extern uint64_t* g_dbg_stamps;
+// diagnostics: lane 0 of wave 0 records the real-time clock at point `i` of its block.  Compiled in only by
+// `make STAMPS=1` (-DMSSR_GEMM_STAMPS=1): even never-taken stamp branches cost the decode sweep 5 % (they pin the
+// instruction schedule around them).
+#ifndef MSSR_GEMM_STAMPS
+#define MSSR_GEMM_STAMPS 0
+#endif
+__device__ __forceinline__ void dbg_stamp(const GemmArgs& p, int i) {
+    if (MSSR_GEMM_STAMPS && p.dbg_stamps && threadIdx.x == 0) {
+        const int64_t b = blockIdx.x + (int64_t)gridDim.x * (blockIdx.y + (int64_t)gridDim.y * blockIdx.z);
+        p.dbg_stamps[b * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    }
+}
 
 // v = alpha*acc (+bias) ; relu ; dropout ; (+residual) ; gate ; (+beta*C_old)
 template <typename TI, typename TO>

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     __shared__ __attribute__((aligned(16))) float red[4 * TE];
     __shared__ float stat[4][TSM][2];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    dbg_stamp(p, 0);
     const int64_t n0 = (int64_t)blockIdx.x * TSN, m0 = (int64_t)blockIdx.y * TSM;
     const int split = blockIdx.z;
     const int64_t steps_total = p.k / 32;
@@ -110,6 +111,8 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             for (int f = 0; f < FM; ++f) fa[g][f] = *reinterpret_cast<const bf16x8*>(A + arow[f] + k);
         }
         __builtin_amdgcn_sched_barrier(0);     // keep the whole batch of loads ahead of the first MFMA
+        dbg_stamp(p, 1);
+        if (MSSR_GEMM_STAMPS && p.dbg_stamps) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); dbg_stamp(p, 2); }
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
             // k-steps past the end were loaded from a clamped address: zero the weight fragments with a
@@ -158,7 +161,9 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
             }
         }
     }
+    dbg_stamp(p, 3);
     __syncthreads();
+    dbg_stamp(p, 4);
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         if (!eok[i]) continue;
@@ -190,6 +195,335 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
         if (p.beta != 0.f) v += p.beta * cold[i];
         reinterpret_cast<TO*>(p.c)[erow * p.ldc + ecol] = from_f<TO>(v);
     }
+    dbg_stamp(p, 5);
+}
+
+// ---- the same product with the operands staged through LDS by DMA (global_load_lds_dwordx4)
+// In-kernel stamps (tools/stamp_bench.py) showed where the register form above spends a launch: not in waiting for
+// memory but in ISSUING its loads.  An MFMA-fragment-shaped load (16 rows x 64 bytes per wave instruction) touches 16
+// cache lines and uses half of each; the CU's address path takes ~245 cycles per such instruction with 8 waves on the
+// CU, so the 8 / 24 / 36 loads a wave needs for K = 512 / 1024 / 1536 took 0.9 / 2.3 / 4.2 us of a 4.8 / 6.4 / 7.9 us
+// launch before the first byte was waited for.  Here every wave copies ITS quarter of K of both operand tiles into its
+// own LDS region with whole 128-byte lines per row (8 rows x 128 bytes per DMA instruction, ~60 cycles each, no
+// registers), waits once, and reads the fragments back with ds_read_b128 (16-byte chunks XOR-swizzled by the row, as in
+// gemm_pipe.hip: conflict-free for the MFMA lane mapping).  Regions are private to a wave: no block barrier before the
+// MFMAs; afterwards the wave's partial tile overwrites its own region and the four tiles are summed as before.
+// Wave w owns the 64-wide k-blocks [w * kbw, (w + 1) * kbw) of the block's k-range (contiguous quarters).
+__device__ __forceinline__ int sk_swz(int r) { return (r >> 1) & 7; }
+
+// KBW = 64-wide k-blocks per wave (compile time: the fragment reads of all blocks are scheduled ahead of the MFMAs that
+// use them); VEC: the EPT consecutive output columns a thread finishes are read / written as one vector (alignment and
+// n % EPT == 0 checked on the host), else element by element.
+template <typename TO, bool LN, int FM, int FN, int KBW, bool VEC>
+__global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmArgs p, const int region_bytes) {
+    constexpr int TSM = 16 * FM, TSN = 16 * FN;
+    constexpr int TE = TSM * TSN;
+    constexpr int EPT = TE / SK_THREADS;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char sk_smem[];     // the kernel's ONLY LDS object
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    dbg_stamp(p, 0);
+    const int64_t n0 = (int64_t)blockIdx.x * TSN, m0 = (int64_t)blockIdx.y * TSM;
+    const int split = blockIdx.z;
+    const int64_t steps_total = p.k / 32;
+    const int64_t per = (steps_total + p.ksplit - 1) / p.ksplit;
+    const int64_t s_begin = split * per;
+    const int64_t s_end = (s_begin + per < steps_total) ? s_begin + per : steps_total;
+    const int nb = (int)((s_end - s_begin + 1) / 2);            // 64-wide k-blocks of this block's range
+    const int b_lo = wave * KBW;
+
+    const bf16* A = reinterpret_cast<const bf16*>(p.a);
+    const bf16* W = reinterpret_cast<const bf16*>(p.b);
+    unsigned char* region = sk_smem + (size_t)wave * region_bytes;
+    unsigned char* regA = region;
+    unsigned char* regW = region + KBW * TSM * 128;
+    // DMA: lane L of an instruction fills slot L of an 8-row group: row L >> 3, physical 16-byte chunk L & 7, which holds
+    // the logical chunk (L & 7) ^ swz(row)
+    const int drow = lane >> 3, dpc = lane & 7;
+    const int64_t k_last = p.k - 8;
+    {
+        const bf16* asrc[TSM / 8];
+        const bf16* wsrc[TSN / 8];
+        int achunk[TSM / 8], wchunk[TSN / 8];
+#pragma unroll
+        for (int g = 0; g < TSM / 8; ++g) {
+            const int r = g * 8 + drow;
+            const int64_t gr = m0 + r;
+            asrc[g] = A + (gr < p.m ? gr : p.m - 1) * p.a_rs;
+            achunk[g] = (dpc ^ sk_swz(r)) * 8;
+        }
+#pragma unroll
+        for (int g = 0; g < TSN / 8; ++g) {
+            const int r = g * 8 + drow;
+            const int64_t gn = n0 + r;
+            wsrc[g] = W + (gn < p.n ? gn : p.n - 1) * p.b_cs;
+            wchunk[g] = (dpc ^ sk_swz(r)) * 8;
+        }
+#pragma unroll
+        for (int bl = 0; bl < KBW; ++bl) {
+            if (b_lo + bl >= nb) break;                          // wave-uniform: the last wave's range may be short
+            const int64_t k0 = (s_begin + 2 * (int64_t)(b_lo + bl)) * 32;
+#pragma unroll
+            for (int g = 0; g < TSN / 8; ++g) {
+                int64_t k = k0 + wchunk[g];
+                k = k <= k_last ? k : k_last;    // second half past the end (odd count of k-steps): never multiplied
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[g] + k),
+                                                 (__attribute__((address_space(3))) void*)(regW + (bl * TSN + g * 8) * 128), 16, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < TSM / 8; ++g) {
+                int64_t k = k0 + achunk[g];
+                k = k <= k_last ? k : k_last;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[g] + k),
+                                                 (__attribute__((address_space(3))) void*)(regA + (bl * TSM + g * 8) * 128), 16, 0, 0);
+            }
+        }
+    }
+    dbg_stamp(p, 1);
+    // epilogue operands of the EPT consecutive elements this thread finishes, requested behind the DMA
+    const int e0 = threadIdx.x * EPT;
+    const int rl = e0 / TSN;
+    const int64_t erow = m0 + rl, ecol0 = n0 + e0 % TSN;
+    float bias[EPT], res[EPT], gate[EPT], cold[EPT], lns[EPT];
+    bool eok[EPT], keepm[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        eok[i] = erow < p.m && ecol0 + i < p.n;
+        bias[i] = res[i] = cold[i] = lns[i] = 0.f;
+        gate[i] = 1.f;
+        keepm[i] = true;
+    }
+    if (eok[0] && p.ksplit == 1) {
+        if (p.drop_p > 0.f && erow >= p.drop_row0) {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+                if (eok[i]) keepm[i] = drop_keep(eff_seed(p, p.drop_seed), (uint64_t)(erow * p.n + ecol0 + i), p.drop_p);
+        }
+        if (VEC && EPT == 4) {
+            if (p.bias) { const f32x4 t = *reinterpret_cast<const f32x4*>(p.bias + ecol0); bias[0] = t[0]; bias[1] = t[1]; bias[2] = t[2]; bias[3] = t[3]; }
+            if (LN) { const f32x4 t = *reinterpret_cast<const f32x4*>(p.ln_colsum + ecol0); lns[0] = t[0]; lns[1] = t[1]; lns[2] = t[2]; lns[3] = t[3]; }
+            if (p.residual) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.residual) + erow * p.ldr + ecol0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) res[i] = (float)t[i];
+            }
+            if (p.gate) {
+                const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.gate) + erow * p.ldg + ecol0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) gate[i] = (float)t[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) {
+                if (!eok[i]) continue;
+                if (p.bias) bias[i] = p.bias[ecol0 + i];
+                if (LN) lns[i] = p.ln_colsum[ecol0 + i];
+                if (p.residual) res[i] = to_f(reinterpret_cast<const bf16*>(p.residual)[erow * p.ldr + ecol0 + i]);
+                if (p.gate) gate[i] = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol0 + i]);
+            }
+        }
+        if (p.beta != 0.f) {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+                if (eok[i]) cold[i] = to_f(reinterpret_cast<const TO*>(p.c)[erow * p.ldc + ecol0 + i]);
+        }
+    }
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float sx[FM], sxx[FM];
+#pragma unroll
+    for (int f = 0; f < FM; ++f) sx[f] = sxx[f] = 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's region is complete (and only it reads it)
+    dbg_stamp(p, 2);
+    const int fr = lane & 15, fc = lane >> 4;
+#pragma unroll
+    for (int bl = 0; bl < KBW; ++bl) {
+        if (b_lo + bl >= nb) break;                              // wave-uniform
+        const unsigned char* tA = regA + bl * TSM * 128;
+        const unsigned char* tW = regW + bl * TSN * 128;
+        bf16x8 fa[2][FM], fb[2][FN];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int r = i * 16 + fr;
+                fa[h][i] = *reinterpret_cast<const bf16x8*>(tA + r * 128 + (((h * 4 + fc) ^ sk_swz(r)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                const int r = j * 16 + fr;
+                fb[h][j] = *reinterpret_cast<const bf16x8*>(tW + r * 128 + (((h * 4 + fc) ^ sk_swz(r)) << 4));
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            // odd count of k-steps: the last block's second half is absent -- its weight fragments are zeroed (uniform)
+            const bool live = s_begin + 2 * (int64_t)(b_lo + bl) + h < s_end;
+            const unsigned msk = live ? 0xffffffffu : 0u;
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                u32x4 wb = __builtin_bit_cast(u32x4, fb[h][j]);
+                wb &= msk;
+                const bf16x8 fbm = __builtin_bit_cast(bf16x8, wb);
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[h][i], fbm, acc[i][j], 0, 0, 0);
+            }
+            if (LN && live) {
+#pragma unroll
+                for (int f = 0; f < FM; ++f)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float x = (float)fa[h][f][j];
+                        sx[f] += x;
+                        sxx[f] += x * x;
+                    }
+            }
+        }
+    }
+    // partial tile -> the wave's own region (its fragment reads are complete: the MFMAs consumed them), then the row
+    // statistics behind it
+    float* red = reinterpret_cast<float*>(region);
+    float* stat = red + TE;                                      // [TSM][2]
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[(i * 16 + (lane >> 4) * 4 + r) * TSN + j * 16 + (lane & 15)] = acc[i][j][r];
+    if (LN) {
+#pragma unroll
+        for (int f = 0; f < FM; ++f) {
+            sx[f] += __shfl_xor(sx[f], 16, 64);
+            sx[f] += __shfl_xor(sx[f], 32, 64);
+            sxx[f] += __shfl_xor(sxx[f], 16, 64);
+            sxx[f] += __shfl_xor(sxx[f], 32, 64);
+            if (lane < 16) {
+                stat[(f * 16 + lane) * 2] = sx[f];
+                stat[(f * 16 + lane) * 2 + 1] = sxx[f];
+            }
+        }
+    }
+    dbg_stamp(p, 3);
+    __syncthreads();
+    dbg_stamp(p, 4);
+    const int rstride = region_bytes / 4;                        // floats between the waves' regions
+    const float* red0 = reinterpret_cast<const float*>(sk_smem);
+    if (!eok[0]) return;
+    float v[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) v[i] = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        if (EPT == 4) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(red0 + w * rstride + e0);
+            v[0] += t[0]; v[1 % EPT] += t[1]; v[2 % EPT] += t[2]; v[3 % EPT] += t[3];
+        } else {
+#pragma unroll
+            for (int i = 0; i < EPT; ++i) v[i] += red0[w * rstride + e0 + i];
+        }
+    }
+    if (p.ksplit > 1) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if (eok[i]) p.partial[((int64_t)split * p.m + erow) * p.n + ecol0 + i] = v[i];
+        return;
+    }
+    float mean = 0.f, rstd = 1.f;
+    if (LN) {
+        const float* st = red0 + TE + rl * 2;
+        const float s1 = (st[0] + st[rstride]) + (st[2 * rstride] + st[3 * rstride]);
+        const float s2 = (st[1] + st[rstride + 1]) + (st[2 * rstride + 1] + st[3 * rstride + 1]);
+        mean = s1 / (float)p.k;
+        const float var = fmaxf(s2 / (float)p.k - mean * mean, 0.f);
+        rstd = rsqrtf(var + p.ln_eps);
+        if (blockIdx.x == 0 && (e0 % TSN) == 0) {
+            if (p.ln_mean) p.ln_mean[erow] = mean;
+            if (p.ln_rstd) p.ln_rstd[erow] = rstd;
+        }
+    }
+    const float keep_scale = 1.0f / (1.0f - p.drop_p);
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        float x = v[i];
+        if (LN) x = rstd * (x - mean * lns[i]);
+        x = p.alpha * x + bias[i];
+        if (p.relu) x = fmaxf(x, 0.f);
+        if (p.drop_p > 0.f && erow >= p.drop_row0) x = keepm[i] ? x * keep_scale : 0.f;
+        x += res[i];
+        if (p.gate) x = gate[i] > 0.f ? x : 0.f;
+        if (p.beta != 0.f) x += p.beta * cold[i];
+        v[i] = x;
+    }
+    TO* crow = reinterpret_cast<TO*>(p.c) + erow * p.ldc + ecol0;
+    if (VEC && EPT == 4) {
+        if constexpr (sizeof(TO) == 2) {
+            bf16x4 o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i % EPT];
+            *reinterpret_cast<bf16x4*>(crow) = o;
+        } else {
+            *reinterpret_cast<f32x4*>(crow) = f32x4{v[0], v[1 % EPT], v[2 % EPT], v[3 % EPT]};
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i)
+            if (eok[i]) crow[i] = from_f<TO>(v[i]);
+    }
+    dbg_stamp(p, 5);
+}
+
+// LDS bytes of one wave's region: its k-blocks of both operand tiles (and, later, its partial tile + row statistics)
+template <int FM, int FN>
+static int sk_dma_region(int kbw) {
+    const int stage = kbw * (16 * FM + 16 * FN) * 128;
+    const int tail = 16 * FM * 16 * FN * 4 + 16 * FM * 2 * 4;
+    return ((stage > tail ? stage : tail) + 1023) & ~1023;
+}
+
+// true when the DMA form was launched (false: the LDS regions do not fit / an unusual k-block count -- the register
+// form takes the problem)
+template <typename TO, bool LN, int FM, int FN, int KBW, bool VEC>
+static bool skinny_dma_go(const GemmArgs& a, const dim3 grid, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    const int region = sk_dma_region<FM, FN>(KBW);
+    const int lds = 4 * region;
+    if (lds > 160 * 1024) return false;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_dma_kernel<TO, LN, FM, FN, KBW, VEC>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (lds > 64 * 1024 && !attr_ok) return false;
+    klaunch_events(gemm_skinny_dma_kernel<TO, LN, FM, FN, KBW, VEC>, grid, dim3(SK_THREADS), (unsigned)lds, s, e0, e1, a, region);
+    return true;
+}
+
+template <typename TO, bool LN, int FM, int FN>
+static bool skinny_dma_launch(const GemmArgs& a, const dim3 grid, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    static const bool enabled = [] { const char* e = getenv("MSSR_SKINNY_DMA"); return !e || atoi(e) != 0; }();
+    static const bool splitk_too = [] { const char* e = getenv("MSSR_SKINNY_DMA_SPLITK"); return e && atoi(e) != 0; }();
+    if (!enabled || (a.ksplit > 1 && !splitk_too)) return false;      // split-K slabs (K = 9632): 25.8 -> 35.3 us with DMA
+    const int64_t steps = (a.k / 32 + a.ksplit - 1) / a.ksplit;
+    const int nb = (int)((steps + 1) / 2), kbw = (nb + 3) / 4;
+    // vector epilogue (4 consecutive columns per thread): 32 x 32 tiles only
+    constexpr int EPT = 16 * FM * 16 * FN / SK_THREADS;
+    bool vec = EPT == 4 && a.n % 4 == 0 && a.ldc % 4 == 0 && aligned(a.c, 16) && (!a.bias || aligned(a.bias, 16)) &&
+               (!a.ln_colsum || aligned(a.ln_colsum, 16)) && (!a.residual || (aligned(a.residual, 8) && a.ldr % 4 == 0)) &&
+               (!a.gate || (aligned(a.gate, 8) && a.ldg % 4 == 0));
+#define SK_DMA_CASE(KB)                                                                                     \
+    case KB:                                                                                                \
+        return vec ? skinny_dma_go<TO, LN, FM, FN, KB, true>(a, grid, s, e0, e1)                            \
+                   : skinny_dma_go<TO, LN, FM, FN, KB, false>(a, grid, s, e0, e1)
+    switch (kbw) {
+        SK_DMA_CASE(1);
+        SK_DMA_CASE(2);
+        SK_DMA_CASE(3);
+        SK_DMA_CASE(4);
+        SK_DMA_CASE(6);
+        SK_DMA_CASE(8);
+        default: return false;
+    }
+#undef SK_DMA_CASE
 }
 
 template <typename TO>
@@ -311,6 +645,7 @@ static int skinny_group(const GemmArgs& a, int tile) {
 
 template <typename TO, bool LN, int FN>
 static void skinny_launch_g(const GemmArgs& a, const dim3 grid, int group, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    if (skinny_dma_launch<TO, LN, 1, FN>(a, grid, s, e0, e1)) return;
     if (group == 8) klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 8>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
     else if (group == 12) klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 12>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
     else klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
@@ -328,9 +663,14 @@ static void skinny_launch(const GemmArgs& a, hipStream_t s) {
         const char* e = getenv("MSSR_SKINNY_16X32_MINK");
         return e ? (int64_t)atoll(e) : (int64_t)1024;
     }();
+    static const bool ln_wide = [] { const char* e = getenv("MSSR_SKINNY_LN_16X32"); return e && atoi(e) != 0; }();
     if (tile == 16 && !a.ln_colsum && a.ksplit == 1 && a.k >= wide_min_k && a.n % 32 == 0 && a.m >= 64) {
         const dim3 grid((unsigned)(a.n / 32), (unsigned)((a.m + 15) / 16), 1);
         skinny_launch_g<TO, false, 2>(a, grid, skinny_group(a, tile), s, e0, e1_main);
+    } else if (ln_wide && a.ln_colsum && a.ksplit == 1 && a.n >= 1024 && a.n % 32 == 0 && a.m <= 512) {
+        // EXPERIMENT: LayerNorm-folded wide products (QKV, FFN inner) on 16 x 32 tiles instead of 32 x 32
+        const dim3 grid((unsigned)(a.n / 32), (unsigned)((a.m + 15) / 16), 1);
+        skinny_launch_g<TO, true, 2>(a, grid, skinny_group(a, 16), s, e0, e1_main);
     } else if (tile == 16) {
         const dim3 grid((unsigned)((a.n + 15) / 16), (unsigned)((a.m + 15) / 16), (unsigned)a.ksplit);
         const int g = skinny_group(a, tile);
@@ -338,8 +678,12 @@ static void skinny_launch(const GemmArgs& a, hipStream_t s) {
         else skinny_launch_g<TO, false, 1>(a, grid, g, s, e0, e1_main);
     } else {
         const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
-        if (a.ln_colsum) klaunch_events(gemm_skinny_kernel<TO, true, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
-        else klaunch_events(gemm_skinny_kernel<TO, false, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+        if (a.ln_colsum) {
+            if (!skinny_dma_launch<TO, true, 2, 2>(a, grid, s, e0, e1_main))
+                klaunch_events(gemm_skinny_kernel<TO, true, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+        } else if (!skinny_dma_launch<TO, false, 2, 2>(a, grid, s, e0, e1_main)) {
+            klaunch_events(gemm_skinny_kernel<TO, false, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+        }
     }
     if (a.ksplit > 1) {
         int64_t blocks = (a.m * a.n + 255) / 256;

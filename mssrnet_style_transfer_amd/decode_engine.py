@@ -479,6 +479,10 @@ def _late_regime(spec, n_chunks):
     return 0, 0
 
 
+def pk_d(spec):
+    return spec.pack.d
+
+
 class _SoftDecode(Function):
     @staticmethod
     def forward(ctx, spec, mem, *params):
@@ -489,9 +493,10 @@ class _SoftDecode(Function):
             plan.late_step, plan.late_row0, plan.late_fwd = late_step, late_row0, 1
             if spec.save:       # rows the late forward steps skip: finite (zero) where the contractions read them
                 T, B = spec.T, spec.B
-                for name in ("X", "qkv", "actD", "actF", "nf"):
+                for name in ("X", "actD", "actF", "nf"):
                     t = bufs[name]
                     t.view(-1, T, B, t.shape[-1])[:, late_step:, :late_row0].zero_()
+                bufs["qkv"].view(-1, B, T, 3 * pk_d(spec))[:, :late_row0, late_step:].zero_()      # sentence-major slab
                 bufs["stats"].view(-1, T, B)[:, late_step:, :late_row0].zero_()
         _timed_sweep("decode_fwd", lib.mssr_decode_fwd, plan)
         probs = bufs.pop("probs")
@@ -773,7 +778,7 @@ def greedy_decode_ids(model, cfg, memory_bank, src_lengths, max_length, check_ev
                 plan2, bufs2, ids2 = new_plan(sp, mem_cur)
                 NL, Bc, d3 = bufs["qkv"].shape[0], rows.numel(), bufs["qkv"].shape[2]
                 # the survivors' self-attention keys / values of the steps so far, and their last tokens
-                bufs2["qkv"].view(NL, T, n_live, d3)[:, :steps] = bufs["qkv"].view(NL, T, Bc, d3)[:, :steps].index_select(2, keep)
+                bufs2["qkv"].view(NL, n_live, T, d3)[:, :, :steps] = bufs["qkv"].view(NL, Bc, T, d3)[:, :, :steps].index_select(1, keep)
                 ids2[:steps] = ids[:steps].index_select(1, keep)
                 rows = rows.index_select(0, keep)
                 plan, bufs, ids, spec = plan2, bufs2, ids2, sp
