@@ -22,33 +22,68 @@ typedef unsigned lnb_u32x4 __attribute__((ext_vector_type(4)));
 constexpr int LNB_NW = 8;                  // waves per block (two per SIMD: one wave's load / reduce chain hides the other's)
 constexpr int LNB_THREADS = 64 * LNB_NW;
 // 16-column fragments per block tile: template parameter LNB_FN (2, or 4 for wide outputs; see the measurements above)
-constexpr int LNB_G = 2;                   // k-steps per wave (K <= LNB_NW * LNB_G * 32 = 512)
+// Wave w owns the 64-wide k-block w (k-steps 2w, 2w + 1): K <= LNB_NW * 64 = 512.
 
+__device__ __forceinline__ int lnb_swz(int r) { return (r >> 1) & 7; }
+
+// Round 3: the operands come in by LDS-DMA, as in gemm_skinny_dma_kernel (gemm_skinny.hip): the fragment-shaped loads
+// of the first version (16 rows x 64 bytes per instruction, 14 per wave) spent more time being ISSUED than in flight.
+// Every wave copies its 64-wide k-block of dy, x, dres (16 rows x 128 bytes each) and of its W columns into its own
+// LDS region with whole 128-byte lines (10 / 14 DMA instructions), reads the fragments back by ds_read_b128 from a
+// 16-byte-chunk XOR-swizzled image, and later reuses the region for its partial tile.  One LDS object only.
 template <typename TO, int LNB_FN>
-__global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p, const int region_bytes) {
     constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
-    __shared__ __attribute__((aligned(16))) float red[LNB_NW][16][LNB_TSN];
-    __shared__ float stat[LNB_NW][16][2];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char lnb_smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t n0 = (int64_t)blockIdx.x * LNB_TSN, m0 = (int64_t)blockIdx.y * 16;
-    const int64_t steps = p.k / 32;
+    const int steps = (int)(p.k / 32);
     const bf16* DY = reinterpret_cast<const bf16*>(p.a);
     const bf16* W = reinterpret_cast<const bf16*>(p.b);
     const bf16* X = reinterpret_cast<const bf16*>(p.lnb_x);
     const bool has_res = p.lnb_dres != nullptr;
     const bf16* DR = has_res ? reinterpret_cast<const bf16*>(p.lnb_dres) : X;          // unconditional loads
-    const int koff = 8 * (lane >> 4);
-    const int64_t arl = m0 + (lane & 15);
+    unsigned char* region = lnb_smem + (size_t)wave * region_bytes;
+    unsigned char* rDY = region;                 // [16][128 B]
+    unsigned char* rX = region + 2048;
+    unsigned char* rDR = region + 4096;
+    unsigned char* rW = region + 6144;           // [LNB_TSN][128 B]
+    float* rstat = reinterpret_cast<float*>(region + 6144 + LNB_TSN * 128);     // [16][2]
+    const bool wave_live = 2 * wave < steps;     // K < 512: the upper waves own nothing
+    const int64_t k0 = wave_live ? (int64_t)wave * 64 : 0;
+    const int64_t k_last = p.k - 8;
+    {
+        const int drow = lane >> 3, dpc = lane & 7;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int r = g * 8 + drow;
+            const int64_t gr = m0 + r;
+            int64_t k = k0 + (dpc ^ lnb_swz(r)) * 8;
+            k = k <= k_last ? k : k_last;            // second half past the end (odd count of k-steps): never used
+            const int64_t off = (gr < p.m ? gr : p.m - 1) * p.a_rs + k;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DY + off),
+                                             (__attribute__((address_space(3))) void*)(rDY + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+                                             (__attribute__((address_space(3))) void*)(rX + g * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DR + off),
+                                             (__attribute__((address_space(3))) void*)(rDR + g * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < LNB_TSN / 8; ++g) {
+            const int r = g * 8 + drow;
+            const int64_t gn = n0 + r;
+            int64_t k = k0 + (dpc ^ lnb_swz(r)) * 8;
+            k = k <= k_last ? k : k_last;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (gn < p.n ? gn : p.n - 1) * p.b_cs + k),
+                                             (__attribute__((address_space(3))) void*)(rW + g * 1024), 16, 0, 0);
+        }
+    }
+    const int fr = lane & 15, fc = lane >> 4;
+    const int64_t arl = m0 + fr;
     const bool row_ok = arl < p.m;
     const int64_t ar = row_ok ? arl : p.m - 1;
     const int64_t arow = ar * p.a_rs;
-    int64_t wrow[LNB_FN];
-#pragma unroll
-    for (int j = 0; j < LNB_FN; ++j) {
-        const int64_t wn = n0 + j * 16 + (lane & 15);
-        wrow[j] = (wn < p.n ? wn : p.n - 1) * p.b_cs;
-    }
-    // epilogue operands of the elements this thread finishes (e = tid + i*256: row e / LNB_TSN, col e % LNB_TSN)
+    // epilogue operands of the elements this thread finishes (e = tid + i*512: row e / LNB_TSN, col e % LNB_TSN)
     constexpr int EPT = (16 * LNB_TSN + LNB_THREADS - 1) / LNB_THREADS;
     float gate[EPT];
     bool eok[EPT];
@@ -62,44 +97,50 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     }
     const float mu = p.lnb_mean[ar], rs = p.lnb_rstd[ar];
     const uint64_t lnb_seed = eff_seed(p, p.lnb_seed);
-    bf16x8 fb[LNB_G][LNB_FN], fdy[LNB_G], fx[LNB_G], fr[LNB_G];
-    f32x4 g0[LNB_G], g1[LNB_G];
+    // gamma of this lane's k-chunks (half h: k = k0 + 32 h + 8 fc .. + 8)
+    f32x4 g0[2], g1[2];
 #pragma unroll
-    for (int g = 0; g < LNB_G; ++g) {
-        int64_t s = wave + LNB_NW * g;
-        s = s < steps ? s : steps - 1;
-        const int64_t k = s * 32 + koff;
-        fdy[g] = *reinterpret_cast<const bf16x8*>(DY + arow + k);
-        fx[g] = *reinterpret_cast<const bf16x8*>(X + arow + k);
-        fr[g] = *reinterpret_cast<const bf16x8*>(DR + arow + k);
-        g0[g] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k);
-        g1[g] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k + 4);
-#pragma unroll
-        for (int j = 0; j < LNB_FN; ++j) fb[g][j] = *reinterpret_cast<const bf16x8*>(W + wrow[j] + k);
+    for (int h = 0; h < 2; ++h) {
+        int64_t k = k0 + 32 * h + 8 * fc;
+        k = k <= k_last ? k : k_last;
+        g0[h] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k);
+        g1[h] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k + 4);
     }
-    // the dropout decisions depend on indices and the seed only: taken here, in the shadow of the loads above
-    // (the whole sweep's backward: -0.3 ms)
+    // the dropout decisions depend on indices and the seed only: taken here, in the shadow of the loads
     const uint32_t thr = drop_thr16(p.lnb_p);
-    uint32_t kp[LNB_G][4];
+    uint32_t kp[2][4];
 #pragma unroll
-    for (int g = 0; g < LNB_G; ++g) {
-        int64_t s = wave + LNB_NW * g;
-        s = s < steps ? s : steps - 1;
-        const uint64_t i2 = (uint64_t)((ar + p.lnb_row_off) * p.k + s * 32 + koff) >> 1;   // a multiple of 4 pairs
+    for (int h = 0; h < 2; ++h) {
+        const uint64_t i2 = (uint64_t)((ar + p.lnb_row_off) * p.k + k0 + 32 * h + 8 * fc) >> 1;   // a multiple of 4 pairs
 #pragma unroll
-        for (int q = 0; q < 4; ++q) kp[g][q] = p.lnb_p > 0.f ? keep16_pair(lnb_seed, i2 + q, thr) : 3u;
+        for (int q = 0; q < 4; ++q) kp[h][q] = p.lnb_p > 0.f ? keep16_pair(lnb_seed, i2 + q, thr) : 3u;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // row statistics of g = gamma * dy over the whole row: lane partials -> the 4 lanes of a row -> the 4 waves
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8 fb[2][LNB_FN], fdy[2], fx[2], fr_[2];
+    bool live[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        live[h] = 2 * wave + h < steps;
+        const int co = ((h * 4 + fc) ^ lnb_swz(fr)) << 4;
+        fdy[h] = *reinterpret_cast<const bf16x8*>(rDY + fr * 128 + co);
+        fx[h] = *reinterpret_cast<const bf16x8*>(rX + fr * 128 + co);
+        fr_[h] = *reinterpret_cast<const bf16x8*>(rDR + fr * 128 + co);
+#pragma unroll
+        for (int j = 0; j < LNB_FN; ++j) {
+            const int r = j * 16 + fr;
+            fb[h][j] = *reinterpret_cast<const bf16x8*>(rW + r * 128 + (((h * 4 + fc) ^ lnb_swz(r)) << 4));
+        }
+    }
+    // row statistics of g = gamma * dy over the whole row: lane partials -> the 4 lanes of a row -> the 8 waves
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int g = 0; g < LNB_G; ++g) {
-        if (wave + LNB_NW * g < steps) {
+    for (int h = 0; h < 2; ++h) {
+        if (live[h]) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float a = (float)fdy[g][j] * (j < 4 ? g0[g][j] : g1[g][j - 4]);
+                const float a = (float)fdy[h][j] * (j < 4 ? g0[h][j] : g1[h][j - 4]);
                 s1 += a;
-                s2 += a * (((float)fx[g][j] - mu) * rs);
+                s2 += a * (((float)fx[h][j] - mu) * rs);
             }
         }
     }
@@ -108,16 +149,17 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
     s2 += __shfl_xor(s2, 16, 64);
     s2 += __shfl_xor(s2, 32, 64);
     if (lane < 16) {
-        stat[wave][lane][0] = s1;
-        stat[wave][lane][1] = s2;
+        rstat[lane * 2] = s1;
+        rstat[lane * 2 + 1] = s2;
     }
     __syncthreads();
-    const int rl = lane & 15;
+    const int rstride = region_bytes / 4;
+    const float* stat0 = reinterpret_cast<const float*>(lnb_smem + 6144 + LNB_TSN * 128);
     float c1 = 0.f, c2 = 0.f;
 #pragma unroll
     for (int w = 0; w < LNB_NW; ++w) {
-        c1 += stat[w][rl][0];
-        c2 += stat[w][rl][1];
+        c1 += stat0[w * rstride + fr * 2];
+        c2 += stat0[w * rstride + fr * 2 + 1];
     }
     c1 /= (float)p.k;
     c2 /= (float)p.k;
@@ -127,39 +169,40 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
 #pragma unroll
     for (int j = 0; j < LNB_FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int g = 0; g < LNB_G; ++g) {
-        const int64_t sg = wave + LNB_NW * g;
-        const bool live = sg < steps;
-        const int64_t k = (live ? sg : steps - 1) * 32 + koff;
+    for (int h = 0; h < 2; ++h) {
+        const int64_t k = k0 + 32 * h + 8 * fc;
         bf16x8 dxv, dx2v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float a = (float)fdy[g][j] * (j < 4 ? g0[g][j] : g1[g][j - 4]);
-            const float xh = ((float)fx[g][j] - mu) * rs;
-            const float o = (has_res ? (float)fr[g][j] : 0.f) + rs * (a - c1 - xh * c2);
+            const float a = (float)fdy[h][j] * (j < 4 ? g0[h][j] : g1[h][j - 4]);
+            const float xh = ((float)fx[h][j] - mu) * rs;
+            const float o = (has_res ? (float)fr_[h][j] : 0.f) + rs * (a - c1 - xh * c2);
             const bf16 ob = (bf16)o;
             const float ov = (float)ob;               // dx IS stored in bf16: replay from the stored value
-            const float o2 = p.lnb_p > 0.f ? (((kp[g][j >> 1] >> (j & 1)) & 1u) ? ov * sc : 0.f) : ov * p.lnb_extra;
+            const float o2 = p.lnb_p > 0.f ? (((kp[h][j >> 1] >> (j & 1)) & 1u) ? ov * sc : 0.f) : ov * p.lnb_extra;
             dxv[j] = ob;
             dx2v[j] = (bf16)o2;
         }
-        if (writer && live) {
+        if (writer && live[h]) {
             *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.lnb_dx) + arow + k) = dxv;
             if (p.lnb_dx2) *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16*>(p.lnb_dx2) + arow + k) = dx2v;
         }
-        const unsigned msk = live ? 0xffffffffu : 0u;
+        const unsigned msk = live[h] ? 0xffffffffu : 0u;
         lnb_u32x4 ab = __builtin_bit_cast(lnb_u32x4, dx2v);
-        ab &= msk;                                    // a clamped (dead) k-step contributes nothing
+        ab &= msk;                                    // an absent k-step contributes nothing
         const bf16x8 am = __builtin_bit_cast(bf16x8, ab);
 #pragma unroll
-        for (int j = 0; j < LNB_FN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, fb[g][j], acc[j], 0, 0, 0);
+        for (int j = 0; j < LNB_FN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, fb[h][j], acc[j], 0, 0, 0);
     }
-    // partial tiles of the waves -> LDS (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r)
+    // partial tiles of the waves -> their own regions (MFMA C layout: col = lane & 15, row = (lane >> 4)*4 + r); every
+    // fragment read of the region was consumed above, and the other waves read only the statistics words behind it
+    float* red = reinterpret_cast<float*>(region);
 #pragma unroll
     for (int j = 0; j < LNB_FN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) red[wave][(lane >> 4) * 4 + r][j * 16 + (lane & 15)] = acc[j][r];
+        for (int r = 0; r < 4; ++r) red[((lane >> 4) * 4 + r) * LNB_TSN + j * 16 + (lane & 15)] = acc[j][r];
     __syncthreads();
+    const float* red0 = reinterpret_cast<const float*>(lnb_smem);
     TO* C = reinterpret_cast<TO*>(p.c);
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
@@ -168,17 +211,31 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p)
         const int rr = e / LNB_TSN, cc = e % LNB_TSN;
         float v = 0.f;
 #pragma unroll
-        for (int w = 0; w < LNB_NW; ++w) v += red[w][rr][cc];
+        for (int w = 0; w < LNB_NW; ++w) v += red0[w * rstride + e];
         v *= p.alpha;
         if (p.gate) v = gate[i] > 0.f ? v : 0.f;
         C[(m0 + rr) * p.ldc + n0 + cc] = from_f<TO>(v);
     }
 }
 
+template <int LNB_FN>
+static int lnb_region_bytes() { return (6144 + 16 * LNB_FN * 128 + 128 + 1023) & ~1023; }
+
+template <typename TO, int LNB_FN>
+static bool lnb_launch(const GemmArgs& a, const dim3 grid, hipStream_t s) {
+    const int region = lnb_region_bytes<LNB_FN>();
+    const int lds = LNB_NW * region;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lnb_kernel<TO, LNB_FN>),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    if (lds > 64 * 1024 && !attr_ok) return false;
+    klaunch(gemm_lnb_kernel<TO, LNB_FN>, grid, dim3(LNB_THREADS), (unsigned)lds, s, a, region);
+    return true;
+}
+
 bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s) {
     if (!a.lnb_x || !a.lnb_gamma || !a.lnb_mean || !a.lnb_rstd || !a.lnb_dx) return false;
     if (a.bias || a.residual || a.relu || a.drop_p > 0.f || a.beta != 0.f || a.ln_colsum) return false;   // plain epilogue (+ gate)
-    if (a.m < 1 || a.n < 1 || a.k < 32 || a.k % 32 != 0 || a.k > LNB_NW * LNB_G * 32) return false;
+    if (a.m < 1 || a.n < 1 || a.k < 32 || a.k % 32 != 0 || a.k > LNB_NW * 64) return false;
     if (a.a_cs != 1 || a.b_rs != 1 || a.a_rs % 8 != 0 || a.b_cs % 8 != 0) return false;
     if ((a.m + 15) / 16 > 65535) return false;
     if (a.lnb_dres == a.lnb_dx) return false;
@@ -193,14 +250,10 @@ bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s) {
     }();
     if (a.n >= wide_n) {
         const dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 15) / 16), 1);
-        if (out_dtype == MSSR_BF16) klaunch(gemm_lnb_kernel<bf16, 4>, grid, dim3(LNB_THREADS), 0, s, a);
-        else klaunch(gemm_lnb_kernel<float, 4>, grid, dim3(LNB_THREADS), 0, s, a);
-        return true;
+        return out_dtype == MSSR_BF16 ? lnb_launch<bf16, 4>(a, grid, s) : lnb_launch<float, 4>(a, grid, s);
     }
     const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 15) / 16), 1);
-    if (out_dtype == MSSR_BF16) klaunch(gemm_lnb_kernel<bf16, 2>, grid, dim3(LNB_THREADS), 0, s, a);
-    else klaunch(gemm_lnb_kernel<float, 2>, grid, dim3(LNB_THREADS), 0, s, a);
-    return true;
+    return out_dtype == MSSR_BF16 ? lnb_launch<bf16, 2>(a, grid, s) : lnb_launch<float, 2>(a, grid, s);
 }
 
 }  // namespace mssr
