@@ -210,6 +210,8 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
 // MFMAs; afterwards the wave's partial tile overwrites its own region and the four tiles are summed as before.
 // Wave w owns the 64-wide k-blocks [w * kbw, (w + 1) * kbw) of the block's k-range (contiguous quarters).
 __device__ __forceinline__ int sk_swz(int r) { return (r >> 1) & 7; }
+typedef float sk_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 sk_bf16x2 __attribute__((ext_vector_type(2)));
 
 // KBW = 64-wide k-blocks per wave (compile time: the fragment reads of all blocks are scheduled ahead of the MFMAs that
 // use them); VEC: the EPT consecutive output columns a thread finishes are read / written as one vector (alignment and
@@ -310,6 +312,17 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
                 const bf16x4 t = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16*>(p.gate) + erow * p.ldg + ecol0);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) gate[i] = (float)t[i];
+            }
+        } else if (VEC && EPT == 2) {
+            if (p.bias) { const sk_f32x2 t = *reinterpret_cast<const sk_f32x2*>(p.bias + ecol0); bias[0] = t[0]; bias[1 % EPT] = t[1]; }
+            if (LN) { const sk_f32x2 t = *reinterpret_cast<const sk_f32x2*>(p.ln_colsum + ecol0); lns[0] = t[0]; lns[1 % EPT] = t[1]; }
+            if (p.residual) {
+                const sk_bf16x2 t = *reinterpret_cast<const sk_bf16x2*>(reinterpret_cast<const bf16*>(p.residual) + erow * p.ldr + ecol0);
+                res[0] = (float)t[0]; res[1 % EPT] = (float)t[1];
+            }
+            if (p.gate) {
+                const sk_bf16x2 t = *reinterpret_cast<const sk_bf16x2*>(reinterpret_cast<const bf16*>(p.gate) + erow * p.ldg + ecol0);
+                gate[0] = (float)t[0]; gate[1 % EPT] = (float)t[1];
             }
         } else {
 #pragma unroll
@@ -421,6 +434,9 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
         if (EPT == 4) {
             const f32x4 t = *reinterpret_cast<const f32x4*>(red0 + w * rstride + e0);
             v[0] += t[0]; v[1 % EPT] += t[1]; v[2 % EPT] += t[2]; v[3 % EPT] += t[3];
+        } else if (EPT == 2) {
+            const sk_f32x2 t = *reinterpret_cast<const sk_f32x2*>(red0 + w * rstride + e0);
+            v[0] += t[0]; v[1 % EPT] += t[1];
         } else {
 #pragma unroll
             for (int i = 0; i < EPT; ++i) v[i] += red0[w * rstride + e0 + i];
@@ -468,6 +484,14 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
         } else {
             *reinterpret_cast<f32x4*>(crow) = f32x4{v[0], v[1 % EPT], v[2 % EPT], v[3 % EPT]};
         }
+    } else if (VEC && EPT == 2) {
+        if constexpr (sizeof(TO) == 2) {
+            sk_bf16x2 o;
+            o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1 % EPT];
+            *reinterpret_cast<sk_bf16x2*>(crow) = o;
+        } else {
+            *reinterpret_cast<sk_f32x2*>(crow) = sk_f32x2{v[0], v[1 % EPT]};
+        }
     } else {
 #pragma unroll
         for (int i = 0; i < EPT; ++i)
@@ -505,9 +529,9 @@ static bool skinny_dma_launch(const GemmArgs& a, const dim3 grid, hipStream_t s,
     if (!enabled || (a.ksplit > 1 && !splitk_too)) return false;      // split-K slabs (K = 9632): 25.8 -> 35.3 us with DMA
     const int64_t steps = (a.k / 32 + a.ksplit - 1) / a.ksplit;
     const int nb = (int)((steps + 1) / 2), kbw = (nb + 3) / 4;
-    // vector epilogue (4 consecutive columns per thread): 32 x 32 tiles only
+    // vector epilogue (the 4 / 2 consecutive columns of a thread as one access): 32 x 32 and 16 x 32 tiles
     constexpr int EPT = 16 * FM * 16 * FN / SK_THREADS;
-    bool vec = EPT == 4 && a.n % 4 == 0 && a.ldc % 4 == 0 && aligned(a.c, 16) && (!a.bias || aligned(a.bias, 16)) &&
+    bool vec = EPT >= 2 && a.n % 4 == 0 && a.ldc % 4 == 0 && aligned(a.c, 16) && (!a.bias || aligned(a.bias, 16)) &&
                (!a.ln_colsum || aligned(a.ln_colsum, 16)) && (!a.residual || (aligned(a.residual, 8) && a.ldr % 4 == 0)) &&
                (!a.gate || (aligned(a.gate, 8) && a.ldg % 4 == 0));
 #define SK_DMA_CASE(KB)                                                                                     \
@@ -663,12 +687,13 @@ static void skinny_launch(const GemmArgs& a, hipStream_t s) {
         const char* e = getenv("MSSR_SKINNY_16X32_MINK");
         return e ? (int64_t)atoll(e) : (int64_t)1024;
     }();
-    static const bool ln_wide = [] { const char* e = getenv("MSSR_SKINNY_LN_16X32"); return e && atoi(e) != 0; }();
+    static const bool ln_wide = [] { const char* e = getenv("MSSR_SKINNY_LN_16X32"); return !e || atoi(e) != 0; }();
     if (tile == 16 && !a.ln_colsum && a.ksplit == 1 && a.k >= wide_min_k && a.n % 32 == 0 && a.m >= 64) {
         const dim3 grid((unsigned)(a.n / 32), (unsigned)((a.m + 15) / 16), 1);
         skinny_launch_g<TO, false, 2>(a, grid, skinny_group(a, tile), s, e0, e1_main);
     } else if (ln_wide && a.ln_colsum && a.ksplit == 1 && a.n >= 1024 && a.n % 32 == 0 && a.m <= 512) {
-        // EXPERIMENT: LayerNorm-folded wide products (QKV, FFN inner) on 16 x 32 tiles instead of 32 x 32
+        // LayerNorm-folded wide products (QKV, FFN inner) of the decode sweep on 16 x 32 tiles instead of 32 x 32: forward
+        // sweep 14.66 -> 14.51 ms
         const dim3 grid((unsigned)(a.n / 32), (unsigned)((a.m + 15) / 16), 1);
         skinny_launch_g<TO, true, 2>(a, grid, skinny_group(a, 16), s, e0, e1_main);
     } else if (tile == 16) {
