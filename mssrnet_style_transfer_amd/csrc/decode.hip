@@ -325,6 +325,30 @@ __device__ __forceinline__ void cross_group_sum(float (&a)[N]) {
 #undef MSSR_XSTEP
 }
 
+// The same sum for the 8-lanes-per-row layout (lane = 8 r + c, 8 values per lane) WITHOUT the LDS crossbar: a
+// transposing reduction -- v_permlane32_swap / v_permlane16_swap exchange half-waves / 16-lane rows of two registers,
+// so one swap + one add folds a lane bit for TWO values at once and halves the live values; the last bit goes
+// through a DPP rotate.  7 swaps / rotates + 9 adds instead of 8 DPP moves + 16 ds_bpermute + 24 adds
+// (cross_group_sum<3, 8>), and afterwards EVERY lane holds one finished value: element
+// group8_elem(lane) = 4 b3 + 2 b4 + b5 (bk = bit k of the lane index) of its 8-column group c = lane & 7.
+// (inline asm: hipcc 7.2 folds the two results of __builtin_amdgcn_permlane{16,32}_swap into one register when both
+// feed the same add -- v_add v1, v2, v2 -- measured with a standalone probe; the s_nop pads are the instruction's
+// VALU-write wait states, which the compiler cannot see inside the string.)
+__device__ __forceinline__ float group8_transpose_sum(const float (&a)[8], int lane) {
+    float a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], a4 = a[4], a5 = a[5], a6 = a[6], a7 = a[7];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\t"
+                 "v_permlane32_swap_b32 %4, %5\n\tv_permlane32_swap_b32 %6, %7\n\ts_nop 1"
+                 : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));
+    float t0 = a0 + a1, t1 = a2 + a3, t2 = a4 + a5, t3 = a6 + a7;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1"
+                 : "+v"(t0), "+v"(t1), "+v"(t2), "+v"(t3));
+    const float u0 = t0 + t1, u1 = t2 + t3;
+    const float w0 = u0 + dpp_mov<0x128>(u0);
+    const float w1 = u1 + dpp_mov<0x128>(u1);
+    return (lane & 8) ? w1 : w0;
+}
+__device__ __forceinline__ int group8_elem(int lane) { return 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1); }
+
 // rows t0 + i*RPL + r (clamped to n_rows - 1) of a [n_rows, dh] operand with row stride `rs`; `base` already
 // points at this lane's 16-byte column group
 template <typename T, int AT_NL>
@@ -437,8 +461,13 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
         load_chunk<T, AT_NL>(vt, vp, kv_ts, t0, r, RPL, Lk);
         ctxacc(vt, t0);
     }
-    cross_group_sum<LS, E>(acc);
-    if (active && r == 0) R::store(ctx + (int64_t)b * ctx_bs + h * dh + c * E, acc);
+    if constexpr (LS == 3 && E == 8) {        // bf16, 64-wide heads: every lane finishes one element (2-byte store)
+        const float o = group8_transpose_sum(acc, lane);
+        if (active) ctx[(int64_t)b * ctx_bs + h * dh + c * E + group8_elem(lane)] = from_f<T>(o);
+    } else {
+        cross_group_sum<LS, E>(acc);
+        if (active && r == 0) R::store(ctx + (int64_t)b * ctx_bs + h * dh + c * E, acc);
+    }
 }
 
 // Backward (see attn_step_bwd_kernel for the math and the gather form): chunk 0 of K, V, of the later steps'
@@ -592,8 +621,13 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         load_chunk<T, AT_NL>(kt, kp, kv_ts, t0, r, RPL, Lk);
         dqacc(kt, t0);
     }
-    cross_group_sum<LS, E>(acc);
-    if (active && r == 0) R::store(dq + (int64_t)b * dq_bs + h * dh + c * E, acc);
+    if constexpr (LS == 3 && E == 8) {
+        const float o = group8_transpose_sum(acc, lane);
+        if (active) dq[(int64_t)b * dq_bs + h * dh + c * E + group8_elem(lane)] = from_f<T>(o);
+    } else {
+        cross_group_sum<LS, E>(acc);
+        if (active && r == 0) R::store(dq + (int64_t)b * dq_bs + h * dh + c * E, acc);
+    }
     if (!gather) return;
     // dK[step] = sum_i ds_{step+i}[step] q_{step+i} ; dV[step] = sum_i pd_{step+i}[step] dctx_{step+i}
     float gk[E], gv[E];
@@ -620,11 +654,20 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         load_chunk<T, AT_NL>(dt, dcp, dctx_ss, t0, r, RPL, n_rows);
         gacc(qt, dt, t0);
     }
-    cross_group_sum<LS, E>(gk);
-    cross_group_sum<LS, E>(gv);
-    if (active && r == 0) {
-        R::store(dk_out + (int64_t)b * out_bs + h * dh + c * E, gk);
-        R::store(dv_out + (int64_t)b * out_bs + h * dh + c * E, gv);
+    if constexpr (LS == 3 && E == 8) {
+        const float ok = group8_transpose_sum(gk, lane), ov = group8_transpose_sum(gv, lane);
+        if (active) {
+            const int64_t o = (int64_t)b * out_bs + h * dh + c * E + group8_elem(lane);
+            dk_out[o] = from_f<T>(ok);
+            dv_out[o] = from_f<T>(ov);
+        }
+    } else {
+        cross_group_sum<LS, E>(gk);
+        cross_group_sum<LS, E>(gv);
+        if (active && r == 0) {
+            R::store(dk_out + (int64_t)b * out_bs + h * dh + c * E, gk);
+            R::store(dv_out + (int64_t)b * out_bs + h * dh + c * E, gv);
+        }
     }
 }
 
