@@ -86,6 +86,10 @@ class MSSRConfig:
     forced_rows_in_sweep: bool = True
     # not a reference flag: the style critic computes in fp32 even when the compute dtype is bf16
     style_critic_fp32: bool = True
+    # not a reference flag: in the generator phase the critics' own parameters are held out of the graph (the reference
+    # lets autograd accumulate gradients into them that the next train_discriminator zeroes unread,
+    # onmt/trainer_wgan_wh.py:866-869 eval modes + :511-512 zero_grad): no weight-gradient products for them there
+    critics_frozen_in_generator_phase: bool = True
 
     @property
     def d_cls(self):

@@ -347,7 +347,7 @@ class _Matmul(Function):
         da = db = None
         if ctx.needs_input_grad[0]:
             da = _Matmul.apply(dc, b, not ctx.tb, a.dtype)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _skip(b):
             if ctx.tb:
                 db = _Matmul.apply(dc.transpose(-1, -2), a, False, b.dtype)
             elif ctx.a_pad is not None and not (torch.is_grad_enabled() and a.requires_grad):
@@ -444,9 +444,9 @@ class _Linear(Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = _Matmul.apply(dz2, weight, False, x.dtype).view(x.shape)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _skip(weight):
             dw = _Matmul.apply(dz2.transpose(0, 1), x.reshape(-1, x.shape[-1]), False, weight.dtype)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and ctx.needs_input_grad[2] and not _skip(weight):
             db = _Colsum.apply(dz2)
         dres = dy if ctx.has_res and ctx.needs_input_grad[4] else None
         return dx, dw, db, None, dres
@@ -479,6 +479,8 @@ class _LayerNorm(Function):
     def backward(ctx, dy):
         x, gamma, mean, rstd = ctx.saved_tensors
         dx, dg, db = _LayerNormBwd.apply(dy, x, gamma, mean, rstd)
+        if _skip(gamma):
+            dg = db = None
         return dx, dg, db, None
 
 
@@ -798,6 +800,26 @@ class second_order:
 
     def __exit__(self, *exc):
         _tls.second_order = self.prev
+
+
+class input_grads_only:
+    """Context manager for a ``torch.autograd.grad(outputs, x)`` call that wants the gradient of an INPUT only (the
+    critics' input gradient of the WGAN-GP penalty, onmt/trainer_wgan_wh.py:1247-1250, 1315-1318): the backward
+    nodes of the ops above leave out their parameter gradients (weight / bias / LayerNorm gain products), which
+    autograd would compute and then drop -- ``needs_input_grad`` only knows that the parameters require gradients
+    in general, not that this call does not collect them.  A process-wide switch, not a thread-local one: the
+    backward nodes run on autograd's device thread.  Never wrap a ``backward()`` that accumulates into parameters."""
+
+    def __enter__(self):
+        self.prev = _state.get("skip_param_grads", False)
+        _state["skip_param_grads"] = True
+
+    def __exit__(self, *exc):
+        _state["skip_param_grads"] = self.prev
+
+
+def _skip(p):
+    return _state.get("skip_param_grads", False) and isinstance(p, torch.nn.Parameter)
 
 
 class _GainPickBwd(Function):

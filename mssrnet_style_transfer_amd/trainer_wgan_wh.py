@@ -45,6 +45,22 @@ def set_mode(module, training):
     return module
 
 
+class _held_out:
+    """Forward passes inside the block record no gradient for the modules' own parameters (the graph is decided at
+    forward time; the block ends before backward())."""
+
+    def __init__(self, on, *modules):
+        self.ps = [p for m in modules for p in m.parameters() if p.requires_grad] if on else ()
+
+    def __enter__(self):
+        for p in self.ps:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.ps:
+            p.requires_grad_(True)
+
+
 def cal_disc_loss(probs, labels):
     """probs[i, labels[i]] as a [N] tensor (one gather instead of the reference's per-row loop).  ``labels``:
     a device tensor (no host round trip) or a Python list as in the reference."""
@@ -81,7 +97,8 @@ def penalize_gen_style_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10
     inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
     with ops.second_order():
         err = cal_disc_loss(d_model(inter, lengths), labels)
-    g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+    with ops.input_grads_only():
+        g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     if gp_norm_seq:
         return _masked_penalty(g, sequence_mask(lengths, max_len=real.size(1)), k, lamb)
     return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
@@ -94,7 +111,8 @@ def penalize_gen_text_grad(d_model, real, fake, lengths, labels, k=1.0, lamb=10.
     inter = (alpha * real + (1 - alpha) * fake).transpose(0, 1).detach().requires_grad_(True)
     with ops.second_order():
         err = cal_disc_loss(d_model(inter, lengths), labels)
-    g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+    with ops.input_grads_only():
+        g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
     g = g.transpose(0, 1)
     if gp_norm_seq:
         return _masked_penalty(g, sequence_mask(lengths, max_len=x_len), k, lamb)
@@ -380,7 +398,8 @@ class Trainer:
                              critic.encoder.embeddings(torch.cat([probs.to(inter.dtype), inter], 1))], 1)
             picked = self._pick(critic.forward_embedded(emb, text_len.repeat(3)), labels.repeat(3), cfg.gain_mode_t)
         err = picked[2 * B:]
-        g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+        with ops.input_grads_only():
+            g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
         gp = self._penalty(g.transpose(0, 1), text_len, vocab_target.size(0), cfg.wgan_text_k, cfg.wgan_text_lamb)
         gain_real, gain_fake = picked[:B].mean(), picked[B:2 * B].mean()
         self._arm(critic)
@@ -398,7 +417,8 @@ class Trainer:
             picked = self._pick(self._style_logits(torch.cat([real, fake, inter]), lengths.repeat(3)), labels.repeat(3),
                                 cfg.gain_mode_s)
         err = picked[2 * B:]
-        g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+        with ops.input_grads_only():
+            g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
         gp = self._penalty(g, lengths, real.size(1), cfg.wgan_style_k, cfg.wgan_style_lamb)
         gain_real, gain_fake = picked[:B].mean(), picked[B:2 * B].mean()
         self._arm(self.style_discriminator)
@@ -482,10 +502,11 @@ class Trainer:
             rep2, probs, sprobs, _, _ = self._generator_forward_batched(labels, real_src, real_len, tgt_len)
         seq_lens, _ = dec_output_length(probs, cfg)
         lens = seq_lens if not cfg.discr_sent_stop_aware else torch.ones_like(real_len) * max_dec_steps
-        gain_t = self._pick(self.text_discriminator(probs, lens), desired_list, cfg.gain_mode_t).mean()
+        with _held_out(cfg.critics_frozen_in_generator_phase, self.text_discriminator, self.style_discriminator):
+            gain_t = self._pick(self.text_discriminator(probs, lens), desired_list, cfg.gain_mode_t).mean()
+            gain_s = self._pick(self._style_logits(rep2.transpose(0, 1), real_len), desired_list, cfg.gain_mode_s).mean()
         with torch.no_grad():
             acc = self.classifier(probs, lens).argmax(-1).eq(desired).float().mean()
-        gain_s = self._pick(self._style_logits(rep2.transpose(0, 1), real_len), desired_list, cfg.gain_mode_s).mean()
         vl = self.vocab_loss_from_probs(sprobs, vocab_target.contiguous().view(-1), B)
         total = vl - cfg.text_ap_scale * gain_t - cfg.style_ap_scale * gain_s
         self._arm(self.style_generator, self.model)
