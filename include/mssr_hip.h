@@ -226,6 +226,32 @@ int mssr_gp_penalty_fwd(const void* g, int64_t s0, int64_t s1, int n0, int n1, i
 int mssr_gp_penalty_bwd(const void* g, int64_t s0, int64_t s1, int n0, int n1, int d, const uint8_t* mask, int64_t m0,
                         int64_t m1, float k, float lamb, const float* norms, const float* acc, const float* dpen,
                         void* dg, int dtype, void* stream);
+/* ContextReps2's pooling (onmt/style_generator_builder.py:243-256: the second Linear's scores w_fn[2](h) [B, L, 1], the
+ * in-place -inf mask past each sentence's length, softmax over time, weighted sum of the states), one launch:
+ *   s_t = h_t . w2 + b2,  a = softmax over t < lengths[b] of s (0 beyond),  pooled[b] = sum_t a_t x[b, t].
+ * x [B, L, d] and h [B, L, m] (h = relu(w_fn[0](x)), computed by the caller's GEMM) are addressed as
+ * base + b*_bs + t*_ts (elements; features contiguous), so [L, B, .] storage is read in place; w2 float [m], b2 float
+ * [1], lengths int64 [B]; pooled [B, d] and a float [B, L] contiguous.  d % 4 == 0, d <= 1024, L <= 1024.
+ * _bwd: from dp = d(loss)/d(pooled) [B, d] (may be NULL) and q = d(loss)/d(a) float [B, L] (may be NULL; the
+ *   second-order pass produces one): dx [B, L, d] (NULL when dp is), dh [B, L, m], and dw2b2 float [m + 1] (dw2 then
+ *   db2) which the caller ZEROED -- sentences add into it.
+ * _bwd_bwd: the derivative of _bwd for the cotangents ddx (of dx), ddh (of dh), ddw2 float [m], ddb2 float [1] (each may
+ *   be NULL): g_dp [B, d], g_x [B, L, d], g_a float [B, L] (hand it to _bwd as q), g_h [B, L, m] (required with ddw2,
+ *   else may be NULL), g_w2 float [m] ZEROED by the caller (required with ddh).  The WGAN-GP penalties differentiate
+ *   the critics' input gradient (onmt/trainer_wgan_wh.py:1247-1250, 1315-1318), which runs through _bwd. */
+int mssr_ctx_pool_fwd(const void* x, int64_t x_bs, int64_t x_ts, const void* h, int64_t h_bs, int64_t h_ts, const float* w2,
+                      const float* b2, const int64_t* lengths, void* pooled, float* a, int B, int L, int d, int m,
+                      int dtype, void* stream);
+int mssr_ctx_pool_bwd(const void* dp, const float* q, const void* x, int64_t x_bs, int64_t x_ts, const void* h, int64_t h_bs,
+                      int64_t h_ts, const float* w2, const float* a, const int64_t* lengths, void* dx, int64_t dx_bs,
+                      int64_t dx_ts, void* dh, int64_t dh_bs, int64_t dh_ts, float* dw2b2, int B, int L, int d, int m,
+                      int dtype, void* stream);
+int mssr_ctx_pool_bwd_bwd(const void* ddx, int64_t ddx_bs, int64_t ddx_ts, const void* ddh, int64_t ddh_bs, int64_t ddh_ts,
+                          const float* ddw2, const float* ddb2, const void* dp, const float* q, const void* x, int64_t x_bs,
+                          int64_t x_ts, const void* h, int64_t h_bs, int64_t h_ts, const float* w2, const float* a,
+                          const int64_t* lengths, void* g_dp, void* g_x, int64_t gx_bs, int64_t gx_ts, void* g_h,
+                          int64_t gh_bs, int64_t gh_ts, float* g_w2, float* g_a, int B, int L, int d, int m, int dtype,
+                          void* stream);
 /* out[n] (+)= sum over rows of x[rows, n] (Linear bias gradient). */
 int mssr_colsum(const void* x, float* out, int64_t rows, int n, int64_t ldx, int accumulate,
                 int dtype, void* stream);

@@ -132,6 +132,11 @@ SIGNATURES = {
     "mssr_gain_pick_fwd": ([_P, _L, _P, _P, _I, _I, _F, _I, _P], c_int),
     "mssr_gain_pick_bwd": ([_P, _P, _L, _P, _P, _I, _I, _F, _I, _P], c_int),
     "mssr_gain_pick_bwd_bwd": ([_P, _L, _P, _P, _L, _P, _P, _P, _I, _I, _F, _I, _P], c_int),
+    "mssr_ctx_pool_fwd": ([_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P], c_int),
+    "mssr_ctx_pool_bwd": ([_P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _I, _I, _I, _I, _I, _P],
+                          c_int),
+    "mssr_ctx_pool_bwd_bwd": ([_P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _L, _L, _P, _L, _L, _P, _P, _P, _P, _P, _L, _L,
+                               _P, _L, _L, _P, _P, _I, _I, _I, _I, _I, _P], c_int),
     "mssr_gp_penalty_fwd": ([_P, _L, _L, _I, _I, _I, _P, _L, _L, _F, _F, _P, _P, _I, _P], c_int),
     "mssr_gp_penalty_bwd": ([_P, _L, _L, _I, _I, _I, _P, _L, _L, _F, _F, _P, _P, _P, _P, _I, _P], c_int),
     "mssr_colsum": ([_P, _P, _L, _I, _L, _I, _I, _P], c_int),

@@ -924,6 +924,131 @@ def gp_penalty(g, mask, k, lamb):
     return _GpPenalty.apply(g, mask, float(k), float(lamb))
 
 
+def _blf(t):
+    """[B, L, f] tensor, features contiguous -> (tensor, batch stride, time stride): [L, B, f] storage is read in place."""
+    if t.stride(2) != 1 and t.shape[2] > 1:
+        t = t.contiguous()
+    return t, t.stride(0), t.stride(1)
+
+
+def _empty_blf(B, Lx, f, time_major, dtype, device):
+    if time_major:
+        return torch.empty(Lx, B, f, dtype=dtype, device=device).transpose(0, 1)
+    return torch.empty(B, Lx, f, dtype=dtype, device=device)
+
+
+class _CtxPoolBwd(Function):
+    """(dx, dh, dw2, db2) of _CtxPool from the gradients arriving at its two outputs, as an op of its own: the
+    gradient penalty differentiates the critic's input gradient, which runs through here (mssr_ctx_pool_bwd_bwd)."""
+
+    @staticmethod
+    def forward(ctx, dp, q, x, h, w2, b2, a, lengths):
+        ctx.cd = _state["dtype"]
+        ctx.set_materialize_grads(False)
+        xc, xbs, xts = _blf(cast(x))
+        hc, hbs, hts = _blf(cast(h))
+        B, Lx, d = xc.shape
+        m = hc.shape[2]
+        dpc = None if dp is None else cast(dp).contiguous()
+        qc = None if q is None else q.to(torch.float32).contiguous()
+        w32 = _f32(w2.detach()).contiguous()
+        dx = None if dp is None else _empty_blf(B, Lx, d, xbs < xts, xc.dtype, xc.device)
+        dh = _empty_blf(B, Lx, m, hbs < hts, hc.dtype, hc.device)
+        acc = torch.zeros(m + 1, dtype=torch.float32, device=xc.device)
+        L.check(L.load().mssr_ctx_pool_bwd(L.ptr(dpc), L.ptr(qc), xc.data_ptr(), xbs, xts, hc.data_ptr(), hbs, hts,
+                                           w32.data_ptr(), a.data_ptr(), lengths.data_ptr(), L.ptr(dx),
+                                           0 if dx is None else dx.stride(0), 0 if dx is None else dx.stride(1),
+                                           dh.data_ptr(), dh.stride(0), dh.stride(1), acc.data_ptr(), B, Lx, d, m,
+                                           L.dt(xc), L.stream()), "ctx_pool_bwd")
+        ctx.save_for_backward(dp, q, x, h, w2, a, lengths)
+        if dx is not None and dx.dtype != x.dtype:
+            dx = dx.to(x.dtype)
+        if dh.dtype != h.dtype:
+            dh = dh.to(h.dtype)
+        return dx, dh, acc[:m].view(w2.shape).to(w2.dtype), acc[m:].to(b2.dtype)
+
+    @staticmethod
+    @once_differentiable
+    @_in_forward_dtype
+    def backward(ctx, ddx, ddh, ddw2, ddb2):
+        dp, q, x, h, w2, a, lengths = ctx.saved_tensors
+        if ddx is None and ddh is None and ddw2 is None and ddb2 is None:
+            return (None,) * 8
+        xc, xbs, xts = _blf(cast(x))
+        hc, hbs, hts = _blf(cast(h))
+        B, Lx, d = xc.shape
+        m = hc.shape[2]
+        dev = xc.device
+        dpc = None if dp is None else cast(dp).contiguous()
+        qc = None if q is None else q.to(torch.float32).contiguous()
+        w32 = _f32(w2.detach()).contiguous()
+        X, Xbs, Xts = (None, 0, 0) if ddx is None else _blf(cast(ddx))
+        H, Hbs, Hts = (None, 0, 0) if ddh is None else _blf(cast(ddh))
+        W = None if ddw2 is None else ddw2.to(torch.float32).contiguous()
+        beta = None if ddb2 is None else ddb2.to(torch.float32).contiguous()
+        g_dp = torch.empty(B, d, dtype=xc.dtype, device=dev)
+        g_x = _empty_blf(B, Lx, d, xbs < xts, xc.dtype, dev)
+        g_h = None if W is None else _empty_blf(B, Lx, m, hbs < hts, hc.dtype, dev)
+        g_w2 = None if H is None else torch.zeros(m, dtype=torch.float32, device=dev)
+        g_a = torch.empty(B, Lx, dtype=torch.float32, device=dev)
+        L.check(L.load().mssr_ctx_pool_bwd_bwd(
+            L.ptr(X), Xbs, Xts, L.ptr(H), Hbs, Hts, L.ptr(W), L.ptr(beta), L.ptr(dpc), L.ptr(qc), xc.data_ptr(), xbs, xts,
+            hc.data_ptr(), hbs, hts, w32.data_ptr(), a.data_ptr(), lengths.data_ptr(), g_dp.data_ptr(), g_x.data_ptr(),
+            g_x.stride(0), g_x.stride(1), L.ptr(g_h), 0 if g_h is None else g_h.stride(0),
+            0 if g_h is None else g_h.stride(1), L.ptr(g_w2), g_a.data_ptr(), B, Lx, d, m, L.dt(xc), L.stream()),
+            "ctx_pool_bwd_bwd")
+        return (None if dp is None else g_dp.to(dp.dtype), None, g_x.to(x.dtype), None if g_h is None else g_h.to(h.dtype),
+                None if g_w2 is None else g_w2.view(w2.shape).to(w2.dtype), None, g_a, None)
+
+
+class _CtxPool(Function):
+    """ContextReps2 behind its first Linear: scores of the second Linear, length mask, softmax over time, weighted sum
+    (onmt/style_generator_builder.py:250-256) in one launch; also returns the weights a [B, L] (float32), through which
+    the second-order pass hands its gradient back."""
+
+    @staticmethod
+    def forward(ctx, x, h, w2, b2, lengths):
+        ctx.cd = _state["dtype"]
+        ctx.set_materialize_grads(False)
+        xc, xbs, xts = _blf(cast(x))
+        hc, hbs, hts = _blf(cast(h))
+        B, Lx, d = xc.shape
+        m = hc.shape[2]
+        w32, b32 = _f32(w2.detach()).contiguous(), _f32(b2.detach()).contiguous()
+        pooled = torch.empty(B, d, dtype=xc.dtype, device=xc.device)
+        a = torch.empty(B, Lx, dtype=torch.float32, device=xc.device)
+        L.check(L.load().mssr_ctx_pool_fwd(xc.data_ptr(), xbs, xts, hc.data_ptr(), hbs, hts, w32.data_ptr(), b32.data_ptr(),
+                                           lengths.data_ptr(), pooled.data_ptr(), a.data_ptr(), B, Lx, d, m, L.dt(xc),
+                                           L.stream()), "ctx_pool_fwd")
+        ctx.save_for_backward(x, h, w2, b2, a, lengths)
+        return pooled, a
+
+    @staticmethod
+    @_in_forward_dtype
+    def backward(ctx, dp, da):
+        x, h, w2, b2, a, lengths = ctx.saved_tensors
+        if dp is None and da is None:
+            return None, None, None, None, None
+        dx, dh, dw2, db2 = _CtxPoolBwd.apply(dp, da, x, h, w2, b2, a, lengths)
+        if _skip(w2):
+            dw2 = db2 = None
+        return dx, dh, dw2, db2, None
+
+
+def ctx_pool(x, h, w2, b2, lengths):
+    """ContextReps2's pooling of the states x [B, L, d] with h = relu(w_fn[0](x)) [B, L, m]: softmax over the first
+    lengths[b] time steps of h . w2 + b2, weighted sum of x -> [B, d].  x / h may be [L, B, .] storage viewed batch first.
+    Twice differentiable (onmt/style_generator_builder.py:243-256 inside the WGAN-GP penalties)."""
+    L.require_cuda(x, h, w2, b2, lengths)
+    if x.dim() != 3 or h.dim() != 3 or h.shape[:2] != x.shape[:2] or w2.numel() != h.shape[2] or b2.numel() != 1 \
+            or lengths.shape != x.shape[:1]:
+        raise ValueError("ctx_pool: x [B, L, d], h [B, L, m], w2 [1, m], b2 [1], lengths [B] expected (got %s, %s, %s, %s, %s)"
+                         % (tuple(x.shape), tuple(h.shape), tuple(w2.shape), tuple(b2.shape), tuple(lengths.shape)))
+    if lengths.dtype != torch.int64 or not lengths.is_contiguous():
+        lengths = lengths.to(torch.int64).contiguous()
+    return _CtxPool.apply(x, h, w2, b2, lengths)[0]
+
+
 def second_order_active():
     return getattr(_tls, "second_order", False)
 

@@ -31,12 +31,14 @@ class ContextReps2(nn.Module):
         self.w_fn = nn.Sequential(nn.Linear(in_size, hidden_size), nn.ReLU(), nn.Linear(hidden_size, 1))
 
     def forward(self, x_states, src_lengths):
-        B, Lx, _ = x_states.shape
-        h = ops.linear(x_states, self.w_fn[0].weight, self.w_fn[0].bias, relu=True)
-        w = ops.linear(h, self.w_fn[2].weight, self.w_fn[2].bias)               # [B, L, 1]
-        mask = padding_mask(src_lengths, Lx).unsqueeze(1)             # [B, 1, L]
-        ww = ops.softmax(w.view(B, 1, 1, Lx), mask, 1.0)                        # softmax over time
-        return ops.matmul(ww.view(B, 1, Lx), x_states, tb=False).view(B, -1)    # sum_t ww * x
+        w0, w2 = self.w_fn[0], self.w_fn[2]
+        if not x_states.is_contiguous() and x_states.transpose(0, 1).is_contiguous():
+            # an encoder's [L, B, d] memory bank viewed batch first: the GEMM and the pooling read it where it lies
+            h = ops.linear(x_states.transpose(0, 1), w0.weight, w0.bias, relu=True).transpose(0, 1)
+        else:
+            h = ops.linear(x_states, w0.weight, w0.bias, relu=True)
+        # scores w2 . h + b2, -inf past each length, softmax over time, weighted sum: one launch (csrc/pool.hip)
+        return ops.ctx_pool(x_states, h, w2.weight, w2.bias, src_lengths)
 
 
 class StyleClassifier(nn.Module):

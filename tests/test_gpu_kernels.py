@@ -978,6 +978,55 @@ def test_gain_pick_twice_differentiable(ops, sigmoid):
     assert bool(torch.isnan(ops.gain_pick(base[:, :C], bad, ratio, sigmoid)[3]))
 
 
+@pytest.mark.parametrize("dtype,time_major", [(torch.float32, False), (torch.float32, True), (torch.bfloat16, True)])
+def test_ctx_pool_twice_differentiable(ops, dtype, time_major):
+    """ContextReps2 (onmt/style_generator_builder.py:243-256: Linear-ReLU-Linear scores, -inf mask past the length,
+    softmax over time, weighted sum) through ops.linear + ops.ctx_pool against the same composition in torch float64:
+    the pooled states, every first-order gradient, and the gradients of a function of the input gradient (the shape
+    of the WGAN-GP penalty) -- in fp32 at 2e-5, in bf16 within bf16's rounding of the operands."""
+    torch.manual_seed(11)
+    B, Lx, d, m = 9, 13, 64, 33                                 # m odd, as the reference's d / 2 + 1
+    lengths = torch.tensor([13, 1, 7, 12, 13, 2, 5, 9, 10], device="cuda")
+    base = torch.randn(Lx, B, d, device="cuda") if time_major else torch.randn(B, Lx, d, device="cuda")
+    P = [torch.randn(m, d, device="cuda") * 0.2, torch.randn(m, device="cuda") * 0.1, torch.randn(1, m, device="cuda"),
+         torch.randn(1, device="cuda")]
+    wv = torch.randn(B, d, device="cuda")
+    ops.set_compute_dtype(dtype)
+
+    def run(x0, params, pool):
+        x = x0.transpose(0, 1) if time_major else x0
+        z = x + 0.1 * x * x                                    # something upstream with curvature
+        pooled = pool(z, *params)
+        g, = torch.autograd.grad(pooled, x0, wv.to(pooled.dtype), create_graph=True)
+        loss = (g.double() ** 2).sum() * 3.0 + (pooled.double() * pooled.double()).sum()
+        loss.backward()
+        return [pooled.detach(), g.detach(), x0.grad] + [q.grad for q in params]
+
+    def ref_pool(z, w1, b1, w2, b2):
+        h = torch.relu(z @ w1.t() + b1)
+        sc = (h @ w2.t() + b2).squeeze(2)
+        t = torch.arange(Lx, device="cuda").unsqueeze(0)
+        sc = sc.masked_fill(t >= lengths.unsqueeze(1), float("-inf"))
+        return (torch.softmax(sc, 1).unsqueeze(2) * z).sum(1)
+
+    def our_pool(z, w1, b1, w2, b2):
+        return ops.ctx_pool(z, ops.linear(z, w1, b1, relu=True), w2, b2, lengths)
+
+    got = run(base.clone().requires_grad_(True), [q.clone().requires_grad_(True) for q in P], our_pool)
+    want = run(base.double().requires_grad_(True), [q.double().requires_grad_(True) for q in P], ref_pool)
+    tol = 2e-5 if dtype == torch.float32 else 3e-2
+    names = ("pooled", "input gradient", "x.grad (second order)", "w1.grad", "b1.grad", "w2.grad", "b2.grad")
+    for a, b, name in zip(got, want, names):
+        assert a is not None, name
+        # b2 shifts every score of a sentence alike and the softmax ignores it: its exact gradient is 0
+        assert_close(a.float(), b.float(), tol, "ctx_pool " + name, floor=1e-3 if name == "b2.grad" else 0.0)
+    # rows past a sentence's length receive no gradient at all
+    xg = got[2].transpose(0, 1) if time_major else got[2]
+    assert float(xg[1, 1:].abs().max()) == 0.0 and float(xg[5, 2:].abs().max()) == 0.0
+    with pytest.raises(RuntimeError):
+        ops.ctx_pool(base.cpu(), base.cpu(), P[2].cpu(), P[3].cpu(), lengths.cpu())   # no CPU path
+
+
 @pytest.mark.parametrize("M,N,K", [(240, 512, 512), (80, 512, 256), (37, 130, 48), (1, 4, 16), (1000, 64, 1024)])
 def test_gemm_skinny_f32_kernel(ops, M, N, K):
     """fp32 K-split kernel (exact f32 MFMA; the style critic's fp32 island and the fp32 parity runs): plain product,
