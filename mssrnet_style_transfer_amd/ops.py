@@ -304,6 +304,29 @@ def _long_k_nn(a, w, out_dtype):
     return gemm(ap, wt, True, out_dtype), ap
 
 
+_zero_arena = {}
+_zero_lock = threading.Lock()
+_ZERO_ARENA = 1 << 20          # floats per arena (4 MB)
+
+
+def zeros_f32(n, device):
+    """n zeroed floats for a kernel that ADDS into its output (bias-gradient column sums, the pooling's and the
+    penalty's accumulators): a slice of a 4 MB arena that one fill zeroed, instead of one fill launch per output --
+    the critics' phase made ~45 such launches of a few hundred bytes each.  Slices are handed out once; an arena lives
+    while any of its slices does.  Per (device, stream): the fill is ordered before its users on that stream."""
+    if n > 65536:
+        return torch.zeros(n, dtype=torch.float32, device=device)
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    take = (n + 63) // 64 * 64
+    with _zero_lock:
+        ent = _zero_arena.get(key)
+        if ent is None or ent[1] + take > _ZERO_ARENA:
+            ent = _zero_arena[key] = [torch.zeros(_ZERO_ARENA, dtype=torch.float32, device=device), 0]
+        off = ent[1]
+        ent[1] = off + take
+    return ent[0][off:off + n]
+
+
 class _Matmul(Function):
     """C = A @ B (tb=False, B [.., K, N]) or A @ B^T (tb=True, B [.., N, K]); closed under autograd."""
 
@@ -397,9 +420,9 @@ class _Colsum(Function):
         if x2.stride(-1) != 1:
             x2 = x2.contiguous()
         ctx.shape, ctx.dtype = x.shape, x.dtype
-        out = torch.empty(x2.shape[1], dtype=torch.float32, device=x.device)
+        out = zeros_f32(x2.shape[1], x.device)
         L.check(L.load().mssr_colsum(x2.data_ptr(), out.data_ptr(), x2.shape[0], x2.shape[1],
-                                     x2.stride(0) if x2.shape[0] > 1 else x2.shape[1], 0, L.dt(x2), L.stream()),
+                                     x2.stride(0) if x2.shape[0] > 1 else x2.shape[1], 1, L.dt(x2), L.stream()),
                 "colsum")
         return out
 
@@ -891,7 +914,7 @@ class _GpPenalty(Function):
         n0, n1, d = g.shape
         m8 = mask.view(torch.uint8)
         norms = torch.empty(n0 * n1, dtype=torch.float32, device=g.device)
-        acc = torch.zeros(4, dtype=torch.float32, device=g.device)
+        acc = zeros_f32(4, g.device)
         L.check(L.load().mssr_gp_penalty_fwd(g.data_ptr(), g.stride(0), g.stride(1), n0, n1, d, m8.data_ptr(), m8.stride(0),
                                              m8.stride(1), k, lamb, norms.data_ptr(), acc.data_ptr(), L.dt(g), L.stream()),
                 "gp_penalty_fwd")
@@ -954,7 +977,7 @@ class _CtxPoolBwd(Function):
         w32 = _f32(w2.detach()).contiguous()
         dx = None if dp is None else _empty_blf(B, Lx, d, xbs < xts, xc.dtype, xc.device)
         dh = _empty_blf(B, Lx, m, hbs < hts, hc.dtype, hc.device)
-        acc = torch.zeros(m + 1, dtype=torch.float32, device=xc.device)
+        acc = zeros_f32(m + 1, xc.device)
         L.check(L.load().mssr_ctx_pool_bwd(L.ptr(dpc), L.ptr(qc), xc.data_ptr(), xbs, xts, hc.data_ptr(), hbs, hts,
                                            w32.data_ptr(), a.data_ptr(), lengths.data_ptr(), L.ptr(dx),
                                            0 if dx is None else dx.stride(0), 0 if dx is None else dx.stride(1),
@@ -989,7 +1012,7 @@ class _CtxPoolBwd(Function):
         g_dp = torch.empty(B, d, dtype=xc.dtype, device=dev)
         g_x = _empty_blf(B, Lx, d, xbs < xts, xc.dtype, dev)
         g_h = None if W is None else _empty_blf(B, Lx, m, hbs < hts, hc.dtype, dev)
-        g_w2 = None if H is None else torch.zeros(m, dtype=torch.float32, device=dev)
+        g_w2 = None if H is None else zeros_f32(m, dev)
         g_a = torch.empty(B, Lx, dtype=torch.float32, device=dev)
         L.check(L.load().mssr_ctx_pool_bwd_bwd(
             L.ptr(X), Xbs, Xts, L.ptr(H), Hbs, Hts, L.ptr(W), L.ptr(beta), L.ptr(dpc), L.ptr(qc), xc.data_ptr(), xbs, xts,

@@ -378,6 +378,19 @@ class Trainer:
             return _masked_penalty(g, sequence_mask(lengths, max_len=max_len), k, lamb)
         return ((g.norm(2, dim=1) - k) ** 2).mean() * lamb
 
+    def _critic_weights(self, B, like):
+        """Row weights of a batched critic pass [real | fake | interpolated]: the cotangent that selects the
+        interpolated rows (grad_outputs of the penalty's input gradient) and the first-order objective
+        mean(fake) - mean(real) as a dot product -- no slices of the gains, whose backward passes are a fill and a
+        copy each."""
+        key = (B, like.device, like.dtype)
+        hit = getattr(self, "_cw", None)
+        if hit is None or hit[0] != key:
+            w_err = torch.cat([like.new_zeros(2 * B), like.new_ones(B)])
+            w_obj = torch.cat([like.new_full((B,), -1.0 / B), like.new_full((B,), 1.0 / B), like.new_zeros(B)])
+            self._cw = hit = (key, w_err, w_obj)
+        return hit[1], hit[2]
+
     def _text_critic_batched(self, vocab_target, probs, text_len, labels, alpha_t):
         """The text critic's three passes of train_discriminator (real ids :545-551, fake soft words :553-560,
         interpolated :562-569 / :1283-1331) as ONE pass on [T, 3B] rows: the real ids go through the embedding lookup
@@ -397,14 +410,14 @@ class Trainer:
             emb = torch.cat([critic.encoder.embeddings(vocab_target),
                              critic.encoder.embeddings(torch.cat([probs.to(inter.dtype), inter], 1))], 1)
             picked = self._pick(critic.forward_embedded(emb, text_len.repeat(3)), labels.repeat(3), cfg.gain_mode_t)
-        err = picked[2 * B:]
+        w_err, w_obj = self._critic_weights(B, picked)
         with ops.input_grads_only():
-            g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+            g, = torch.autograd.grad(picked, inter, w_err, create_graph=True, retain_graph=True)
         gp = self._penalty(g.transpose(0, 1), text_len, vocab_target.size(0), cfg.wgan_text_k, cfg.wgan_text_lamb)
-        gain_real, gain_fake = picked[:B].mean(), picked[B:2 * B].mean()
+        gains = picked.detach().view(3, B)[:2].mean(1)
         self._arm(critic)
-        (gain_fake - gain_real + gp).backward()
-        return gain_real, gain_fake, gp
+        (torch.dot(picked, w_obj) + gp).backward()
+        return gains[0], gains[1], gp
 
     def _style_critic_batched(self, real_rep_t, gen_rep_t, lengths, labels, alpha_s):
         """The style critic on real, generated and interpolated representations [B, L, dim] in one pass (:571-620)."""
@@ -416,14 +429,14 @@ class Trainer:
         with ops.second_order():
             picked = self._pick(self._style_logits(torch.cat([real, fake, inter]), lengths.repeat(3)), labels.repeat(3),
                                 cfg.gain_mode_s)
-        err = picked[2 * B:]
+        w_err, w_obj = self._critic_weights(B, picked)
         with ops.input_grads_only():
-            g, = torch.autograd.grad(err, inter, torch.ones_like(err), create_graph=True, retain_graph=True)
+            g, = torch.autograd.grad(picked, inter, w_err, create_graph=True, retain_graph=True)
         gp = self._penalty(g, lengths, real.size(1), cfg.wgan_style_k, cfg.wgan_style_lamb)
-        gain_real, gain_fake = picked[:B].mean(), picked[B:2 * B].mean()
+        gains = picked.detach().view(3, B)[:2].mean(1)
         self._arm(self.style_discriminator)
-        (gain_fake - gain_real + gp).backward()
-        return gain_real, gain_fake, gp
+        (torch.dot(picked, w_obj) + gp).backward()
+        return gains[0], gains[1], gp
 
     def _finish_discriminator(self, gain_t_real, gain_t_fake, t_gp, gain_s_real, gain_s_fake, s_gp):
         self._finish((self.style_discriminator, self.text_discriminator),

@@ -1,7 +1,7 @@
 """Which Python lines issue aten ops that launch kernels which are NOT ours (at::native elementwise / reduce / cat /
 copies / fills, hipBLASLt) in one WGAN step.  A TorchDispatchMode counts every non-view aten call by
 (op, innermost frame inside the package); autograd worker threads inherit the mode.
-python tools/native_ops.py [--workload wgan|reconstruct]"""
+python tools/native_ops.py [--workload wgan|reconstruct] [--dphase]"""
 import collections
 import os
 import sys
@@ -55,9 +55,20 @@ def main():
         step()
     torch.cuda.synchronize()
     c = Count()
-    with c:
+    if "--dphase" in sys.argv:          # only the critics' phase of the step (its backward runs inside the call)
+        inner = trainer.train_discriminator
+
+        def counted(*a, **k):
+            with c:
+                out = inner(*a, **k)
+                torch.cuda.synchronize()
+            return out
+        trainer.train_discriminator = counted
         step()
-        torch.cuda.synchronize()
+    else:
+        with c:
+            step()
+            torch.cuda.synchronize()
     tot = sum(v[0] for v in c.agg.values())
     print("aten calls that may launch: %d" % tot)
     for (op, where), (n, shp) in sorted(c.agg.items(), key=lambda kv: -kv[1][0])[:160]:
