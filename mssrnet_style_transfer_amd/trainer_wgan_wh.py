@@ -218,6 +218,9 @@ class Trainer:
 
     def unpack_batch(self, batch):
         cfg = self.cfg
+        held = getattr(self, "_unpacked", None)
+        if held is not None and held[0] is batch:       # train_wgan_step: one unpacking for its three users
+            return held[1]
         src, src_lengths = batch.src, batch.src_lengths
         real_src = src[1:]
         real_len = src_lengths - 1
@@ -401,19 +404,24 @@ class Trainer:
         cfg = self.cfg
         B = labels.numel()
         critic = self.text_discriminator
+        T = vocab_target.size(0)
         with torch.no_grad():
-            real_onehot = convert_sent_ids_to_onehot(vocab_target.transpose(0, 1).squeeze(2), cfg.vocab_size)
-            alpha = _to_device_async(alpha_t, real_onehot)
-            inter = (alpha * real_onehot + (1 - alpha) * probs.transpose(0, 1)).transpose(0, 1)
-        inter = inter.detach().requires_grad_(True)                                   # [T, B, V]
+            # soft words [T, 2B, V] = fake | interpolated, written in place (no concatenation).  alpha * onehot(real) +
+            # (1 - alpha) * fake (:1298-1300) without the one-hot tensor: the fake words scaled, then alpha added at
+            # each real id
+            alpha = _to_device_async(alpha_t, self.one).view(1, B, 1)
+            soft = torch.empty(T, 2 * B, cfg.vocab_size, dtype=torch.float32, device=probs.device)
+            soft[:, :B].copy_(probs)
+            torch.mul(probs, 1 - alpha, out=soft[:, B:])
+            soft[:, B:].scatter_add_(2, vocab_target, alpha.expand(T, B, 1))
+        soft.requires_grad_(True)      # the critic's sentences are independent: rows B.. of d/d soft are d/d interpolated
         with ops.second_order():
-            emb = torch.cat([critic.encoder.embeddings(vocab_target),
-                             critic.encoder.embeddings(torch.cat([probs.to(inter.dtype), inter], 1))], 1)
+            emb = torch.cat([critic.encoder.embeddings(vocab_target), critic.encoder.embeddings(soft)], 1)
             picked = self._pick(critic.forward_embedded(emb, text_len.repeat(3)), labels.repeat(3), cfg.gain_mode_t)
         w_err, w_obj = self._critic_weights(B, picked)
         with ops.input_grads_only():
-            g, = torch.autograd.grad(picked, inter, w_err, create_graph=True, retain_graph=True)
-        gp = self._penalty(g.transpose(0, 1), text_len, vocab_target.size(0), cfg.wgan_text_k, cfg.wgan_text_lamb)
+            g, = torch.autograd.grad(picked, soft, w_err, create_graph=True, retain_graph=True)
+        gp = self._penalty(g[:, B:].transpose(0, 1), text_len, T, cfg.wgan_text_k, cfg.wgan_text_lamb)
         gains = picked.detach().view(3, B)[:2].mean(1)
         self._arm(critic)
         (torch.dot(picked, w_obj) + gp).backward()
@@ -423,16 +431,20 @@ class Trainer:
         """The style critic on real, generated and interpolated representations [B, L, dim] in one pass (:571-620)."""
         cfg = self.cfg
         B = labels.numel()
-        real, fake = real_rep_t.float(), gen_rep_t.float()
-        alpha = _to_device_async(alpha_s, real)
-        inter = (alpha * real + (1 - alpha) * fake).detach().requires_grad_(True)
+        with torch.no_grad():
+            # real | fake | interpolated rows written in place (fp32): two casting copies and one lerp
+            # (fake + alpha (real - fake) = alpha real + (1 - alpha) fake, :1238-1240), no concatenation
+            x = torch.empty((3 * B,) + tuple(real_rep_t.shape[1:]), dtype=torch.float32, device=real_rep_t.device)
+            x[:B].copy_(real_rep_t)
+            x[B:2 * B].copy_(gen_rep_t)
+            torch.lerp(x[B:2 * B], x[:B], _to_device_async(alpha_s, x), out=x[2 * B:])
+        x.requires_grad_(True)         # sentences are independent in the critic: rows 2B.. of d/dx are d/d interpolated
         with ops.second_order():
-            picked = self._pick(self._style_logits(torch.cat([real, fake, inter]), lengths.repeat(3)), labels.repeat(3),
-                                cfg.gain_mode_s)
+            picked = self._pick(self._style_logits(x, lengths.repeat(3)), labels.repeat(3), cfg.gain_mode_s)
         w_err, w_obj = self._critic_weights(B, picked)
         with ops.input_grads_only():
-            g, = torch.autograd.grad(picked, inter, w_err, create_graph=True, retain_graph=True)
-        gp = self._penalty(g, lengths, real.size(1), cfg.wgan_style_k, cfg.wgan_style_lamb)
+            g, = torch.autograd.grad(picked, x, w_err, create_graph=True, retain_graph=True)
+        gp = self._penalty(g[2 * B:], lengths, x.size(1), cfg.wgan_style_k, cfg.wgan_style_lamb)
         gains = picked.detach().view(3, B)[:2].mean(1)
         self._arm(self.style_discriminator)
         (torch.dot(picked, w_obj) + gp).backward()
@@ -538,7 +550,15 @@ class Trainer:
         cfg = self.cfg
         if not (cfg.ap_gen_self_style_text and cfg.batch_generator_phase and cfg.share_decode_sweep):
             return self.train_discriminator(batch), self.train_generator(batch)
-        labels, labels_list, real_src, real_len, vocab_target = self.unpack_batch(batch)
+        unpacked = self.unpack_batch(batch)
+        labels, labels_list, real_src, real_len, vocab_target = unpacked
+        self._unpacked = (batch, unpacked)
+        try:
+            return self._wgan_step_shared(batch, labels, real_src, real_len, vocab_target)
+        finally:
+            self._unpacked = None
+
+    def _wgan_step_shared(self, batch, labels, real_src, real_len, vocab_target):
         tgt_len = vocab_target.size(0)
         # generator side in train mode: the forward half of train_generator.  What train_discriminator computes in
         # eval mode under no_grad (:530-535: own-style representation -> bonded encoder states -> decoded text) rides
