@@ -562,6 +562,8 @@ int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);
 int mssr_decode_bwd(const mssr_decode_plan* plan, void* stream);
 /* Number of recorded sweeps currently kept (diagnostics, tests).  No reference counterpart. */
 int mssr_decode_graphs(void);
+/* Recordings made since the process started (never decreases: a full cache evicts its least recently used sweep). */
+long mssr_decode_graphs_recorded(void);
 /* Gradient of the memory keys | values of a decode sweep, all layers in one launch: contracts the per-step slabs the
  * backward sweep left in plan.ds_ctx [n_layers][2 = ds|pd][T][B*heads][Ls] (float) with the saved context queries
  * (qc: layer l at qc + l*qc_layer_stride elements, [T][B, d]) and context gradients (dctx, likewise) over the steps:

@@ -1527,6 +1527,7 @@ struct GraphCache {
     uint64_t* words[16] = {};                      // device address of graph_seed_words, per device
     hipStream_t cap_stream[16] = {};
     std::vector<size_t> seen;                      // hashes of plans met once (recorded at the second meeting)
+    long recorded = 0;                             // recordings made since the process started
     uint64_t clock = 0;
 };
 static GraphCache g_graphs;
@@ -1613,6 +1614,7 @@ static bool run_sweep_graphed(const mssr_decode_plan* p, bool backward, hipStrea
             return false;
         }
         S.used = true; S.key = key; S.graph = g; S.exec = ex;
+        ++C.recorded;
         hit = victim;
     }
     SweepGraph& S = C.slot[hit];
@@ -1640,6 +1642,10 @@ static int sweep_graph_count() {
 using namespace mssr;
 
 extern "C" int mssr_decode_graphs(void) { return sweep_graph_count(); }
+extern "C" long mssr_decode_graphs_recorded(void) {
+    std::lock_guard<std::mutex> lock(g_graphs.mu);
+    return g_graphs.recorded;
+}
 
 extern "C" int mssr_decode_step_fwd(const mssr_decode_plan* p, int step, void* stream) {
     MSSR_REQUIRE(p, "decode_step_fwd: null plan");

@@ -411,7 +411,7 @@ def test_recorded_sweeps_replay_bit_identically(ops, dtype, monkeypatch):
     w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
     seeds = iter([1234, 1234, 1234, 1234, 99, 1234])
     monkeypatch.setattr(ops, "next_seed", lambda: next(seeds))
-    before = lib.mssr_decode_graphs()
+    before = lib.mssr_decode_graphs_recorded()
     outs = []
     for _ in range(6):
         model.zero_grad()
@@ -422,7 +422,7 @@ def test_recorded_sweeps_replay_bit_identically(ops, dtype, monkeypatch):
         # results go to the host: device-side copies kept across iterations would change what the allocator hands out
         outs.append((probs.detach().cpu(), m.grad.cpu(), g.cpu()))
         del probs, m, g
-    recorded = lib.mssr_decode_graphs() - before
+    recorded = lib.mssr_decode_graphs_recorded() - before
     # buffers come from torch's caching allocator: the same sizes in the same order return the same blocks, so the
     # plans of calls 2.. match call 1's and both directions were recorded
     assert recorded >= 2, "no sweep was recorded (%d): the plans' buffers moved between identical calls" % recorded
