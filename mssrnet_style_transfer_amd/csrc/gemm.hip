@@ -242,6 +242,7 @@ static void launch(const GemmArgs& a0, int64_t batch0, hipStream_t s) {
 }  // namespace mssr
 
 thread_local const uint64_t* mssr::tl_seed_base = nullptr;
+thread_local int mssr::tl_skinny_choice = 0;
 uint64_t* mssr::g_dbg_stamps = nullptr;
 extern "C" void mssr_debug_stamps(void* buf) { mssr::g_dbg_stamps = (uint64_t*)buf; }
 
@@ -342,7 +343,7 @@ static int gemm_run(const mssr_gemm_desc* d, void* stream, const char* who) {
         MSSR_LAUNCH_OK("gemm(wide)");
     }
     if (!d->no_skinny && gemm_skinny_try(a, d->in_dtype, d->out_dtype, batch, s)) {
-        prof_end(pi, s, 1, d->in_dtype, d->out_dtype, gemm_skinny_tile(d->m, d->n, d->k), batch, d->m, d->n, d->k,
+        prof_end(pi, s, 1, d->in_dtype, d->out_dtype, tl_skinny_choice, batch, d->m, d->n, d->k,
                  gemm_skinny_ksplit(d->k), d->ln_colsum ? 1 : 0);
         MSSR_LAUNCH_OK("gemm(skinny)");
     }

@@ -58,6 +58,9 @@ __device__ __forceinline__ uint64_t eff_seed(const GemmArgs& p, uint64_t s) { re
 // the seed_base every GemmArgs filled on this thread receives (gemm_fill_args); set by the decode engine while it
 // records a sweep, null otherwise
 extern thread_local const uint64_t* tl_seed_base;
+// what the K-split launcher chose for the calling thread's last product (bench records): 100 * (operands staged by
+// LDS-DMA) + 10 * FM + FN for an (16 FM) x (16 FN) tile; 0: the fp32 kernel
+extern thread_local int tl_skinny_choice;
 extern uint64_t* g_dbg_stamps;
 // diagnostics: lane 0 of wave 0 records the real-time clock at point `i` of its block.  Compiled in only by
 // `make STAMPS=1` (-DMSSR_GEMM_STAMPS=1): even never-taken stamp branches cost the decode sweep 5 % (they pin the

@@ -669,7 +669,9 @@ static int skinny_group(const GemmArgs& a, int tile) {
 
 template <typename TO, bool LN, int FN>
 static void skinny_launch_g(const GemmArgs& a, const dim3 grid, int group, hipStream_t s, hipEvent_t e0, hipEvent_t e1) {
+    tl_skinny_choice = 110 + FN;
     if (skinny_dma_launch<TO, LN, 1, FN>(a, grid, s, e0, e1)) return;
+    tl_skinny_choice = 10 + FN;
     if (group == 8) klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 8>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
     else if (group == 12) klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 12>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
     else klaunch_events(gemm_skinny_kernel<TO, LN, 1, FN, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1, a);
@@ -703,10 +705,14 @@ static void skinny_launch(const GemmArgs& a, hipStream_t s) {
         else skinny_launch_g<TO, false, 1>(a, grid, g, s, e0, e1_main);
     } else {
         const dim3 grid((unsigned)((a.n + 31) / 32), (unsigned)((a.m + 31) / 32), (unsigned)a.ksplit);
+        tl_skinny_choice = 122;
         if (a.ln_colsum) {
-            if (!skinny_dma_launch<TO, true, 2, 2>(a, grid, s, e0, e1_main))
+            if (!skinny_dma_launch<TO, true, 2, 2>(a, grid, s, e0, e1_main)) {
+                tl_skinny_choice = 22;
                 klaunch_events(gemm_skinny_kernel<TO, true, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
+            }
         } else if (!skinny_dma_launch<TO, false, 2, 2>(a, grid, s, e0, e1_main)) {
+            tl_skinny_choice = 22;
             klaunch_events(gemm_skinny_kernel<TO, false, 2, 2, 4>, grid, dim3(SK_THREADS), 0, s, e0, e1_main, a);
         }
     }
@@ -746,6 +752,7 @@ bool gemm_skinny_eligible(const GemmArgs& a, int in_dtype, int64_t batch) {
 }
 
 bool gemm_skinny_try(const GemmArgs& a0, int in_dtype, int out_dtype, int64_t batch, hipStream_t s) {
+    tl_skinny_choice = 0;
     if (in_dtype == MSSR_F32) return skinny_f32_try(a0, out_dtype, batch, s);
     if (!gemm_skinny_eligible(a0, in_dtype, batch)) return false;
     GemmArgs a = a0;

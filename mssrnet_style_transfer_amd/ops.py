@@ -259,8 +259,13 @@ def stop_profile():
         elif r.kernel == 2:
             name = "gemm_tn_kernel<%s>" % tout
         elif r.kernel == 1:
-            name = "gemm_skinny_kernel<%s,%s,%d>%s" % (tout, "LN" if r.ln else "noLN", r.tile // 16,
-                                                      "+splitK" if r.ksplit > 1 else "")
+            # r.tile = the launcher's choice: 100 * (operands staged by LDS-DMA) + 10 * FM + FN; 0: the fp32 kernel
+            if r.tile == 0:
+                name = "gemm_skinny_f32_kernel"
+            else:
+                name = "gemm_skinny%s_kernel<%s,%s,%dx%d>%s" % (
+                    "_dma" if r.tile >= 100 else "", tout, "LN" if r.ln else "noLN", 16 * (r.tile % 100 // 10),
+                    16 * (r.tile % 10), "+splitK" if r.ksplit > 1 else "")
         else:
             name = "gemm_kernel<%s,%s,%d>" % (tin, tout, r.tile)
         if r.ms < 0:

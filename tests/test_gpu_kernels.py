@@ -1040,7 +1040,7 @@ def test_gemm_skinny_f32_kernel(ops, M, N, K):
     ops.start_profile()
     got = ops.gemm(a, w, True, torch.float32)
     rec = ops.stop_profile()
-    assert rec and rec[0]["kernel"].startswith("gemm_skinny_kernel<f32"), rec
+    assert rec and rec[0]["kernel"] == "gemm_skinny_f32_kernel", rec
     assert_close(got, want.float(), 2e-6, "f32 K-split plain", floor=1e-6)
     got = ops.gemm(a, w, True, torch.float32, bias=bias, relu=True)
     assert_close(got, torch.relu(want + bias.double()).float(), 2e-6, "f32 K-split bias relu", floor=1e-6)

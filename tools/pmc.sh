@@ -1,13 +1,14 @@
 #!/bin/bash
-# usage: scratch/pmc.sh <counter> <tag>  -- one counter pass over a short bench run; per-kernel means to gpurun_out/
-ctr=$1; tag=$2
+# usage: tools/pmc.sh <counter> <tag> [bench args, e.g. --workload long]  -- one counter pass over a short bench run;
+# per-kernel means to gpurun_out/pmc_<tag>.csv
+ctr=$1; tag=$2; shift 2
 cd /tmp && export TMPDIR=/tmp
 # counter collection serialises every dispatch (minutes for a 7 000-kernel step) and prints nothing meanwhile: a
 # heartbeat file tells the harness the run is alive
 ( while sleep 30; do date >> $GRAFT_REPO_ROOT/gpurun_out/pmc_heartbeat.log; done ) &
 hb=$!
 trap 'kill $hb 2>/dev/null' EXIT
-timeout -s KILL 400 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
+timeout -s KILL 900 rocprofv3 --pmc $ctr --output-format csv -d /tmp/pmc_$tag -o $tag -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline "$@" > $GRAFT_REPO_ROOT/gpurun_out/pmc_$tag.log 2>&1
 rc=$?
 f=$(find /tmp/pmc_$tag -name "*counter_collection.csv" | head -1)
 ls -la /tmp/pmc_$tag/* | head -5

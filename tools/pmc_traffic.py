@@ -11,7 +11,9 @@ request as 64 bytes, so MI355X_MICROARCH.md prescribes doubling it before compar
 bench.py's kernel names (ops.stop_profile) group the instantiations rocprofv3 lists separately (the G template
 parameter = rows per block is not part of the bench name); the groups are summed dispatch-weighted.
 
-    python tools/pmc_traffic.py wgan profiles/r02_pmc_fetch_size.csv profiles/r02_pmc_write_size.csv profiles/r02_pmc_traffic.json
+    python tools/pmc_traffic.py wgan profiles/r02_pmc_fetch_size.csv profiles/r02_pmc_write_size.csv profiles/r02_pmc_traffic.json [sha16]
+
+(sha16: the source hash recorded on the box when the counters were collected, tools/collect_profiles.sh.)
 """
 import csv
 import json
@@ -19,20 +21,39 @@ import os
 import re
 import sys
 
+def _tile(fm, fn):
+    return "%dx%d" % (16 * int(fm), 16 * int(fn))
+
+
+_LN = {"0": "noLN", "1": "LN", "false": "noLN", "true": "LN"}
+
 RULES = [
-    # rocprofv3 leaves names with a __hip_bfloat16 template argument mangled (DF16b); the LN = true instantiation is
-    # demangled, wrongly, as "<bool _Accum, bool, E, F, G>"
-    (re.compile(r"gemm_skinny_kernelIDF16bLb0ELi(\d+)ELi\d+E"), "gemm_skinny_kernel<bf16,noLN,%s>"),
-    (re.compile(r"gemm_skinny_kernelIDF16bLb1ELi(\d+)ELi\d+E"), "gemm_skinny_kernel<bf16,LN,%s>"),
-    (re.compile(r"gemm_skinny_kernel<bool _Accum, bool, E, (\d+), \d+>"), "gemm_skinny_kernel<bf16,LN,%s>"),
-    (re.compile(r"gemm_skinny_kernel<float, false, (\d+), \d+>"), "gemm_skinny_kernel<f32,noLN,%s>"),
-    (re.compile(r"gemm_lnb_kernelIDF16bE"), "gemm_lnb_kernel<bf16>"),
-    (re.compile(r"gemm_lnb_kernel<float>"), "gemm_lnb_kernel<f32>"),
-    (re.compile(r"gemm_tn_kernel<float, \d+>"), "gemm_tn_kernel<f32>"),
-    (re.compile(r"gemm_tn_kernelIDF16bLi\d+E"), "gemm_tn_kernel<bf16>"),
-    (re.compile(r"gemm_kernelIDF16bDF16bLi(\d+)ELi\d+E"), "gemm_kernel<bf16,bf16,%s>"),
-    (re.compile(r"gemm_kernelIDF16bfLi(\d+)ELi\d+E"), "gemm_kernel<bf16,f32,%s>"),
-    (re.compile(r"gemm_kernel<float, float, (\d+), \d+>"), "gemm_kernel<f32,f32,%s>"),
+    # rocprofv3 leaves names with a __hip_bfloat16 template argument mangled (DF16b) unless LN = true, which it demangles,
+    # wrongly, as "<bool _Accum, bool, E, ...>".  K-split GEMM family: <TO, LN, FM, FN, group | k-blocks per wave[, VEC]>
+    (re.compile(r"gemm_skinny_dma_kernelIDF16bLb([01])ELi(\d)ELi(\d)ELi\d+ELb[01]E"),
+     lambda m: "gemm_skinny_dma_kernel<bf16,%s,%s>" % (_LN[m.group(1)], _tile(m.group(2), m.group(3)))),
+    (re.compile(r"gemm_skinny_dma_kernel<bool _Accum, bool, E, (\d), (\d), \d+, (?:true|false)>"),
+     lambda m: "gemm_skinny_dma_kernel<bf16,LN,%s>" % _tile(m.group(1), m.group(2))),
+    (re.compile(r"gemm_skinny_dma_kernel<float, (true|false), (\d), (\d), \d+, (?:true|false)>"),
+     lambda m: "gemm_skinny_dma_kernel<f32,%s,%s>" % (_LN[m.group(1)], _tile(m.group(2), m.group(3)))),
+    (re.compile(r"gemm_skinny_kernelIDF16bLb([01])ELi(\d)ELi(\d)ELi\d+EEE"),
+     lambda m: "gemm_skinny_kernel<bf16,%s,%s>" % (_LN[m.group(1)], _tile(m.group(2), m.group(3)))),
+    (re.compile(r"gemm_skinny_kernel<bool _Accum, bool, E, (\d), (\d), \d+>"),
+     lambda m: "gemm_skinny_kernel<bf16,LN,%s>" % _tile(m.group(1), m.group(2))),
+    (re.compile(r"gemm_skinny_kernel<float, (true|false), (\d), (\d), \d+>"),
+     lambda m: "gemm_skinny_kernel<f32,%s,%s>" % (_LN[m.group(1)], _tile(m.group(2), m.group(3)))),
+    (re.compile(r"gemm_skinny_f32_kernel<\d+>"), lambda m: "gemm_skinny_f32_kernel"),
+    (re.compile(r"gemm_lnb_kernelIDF16bLi\d+E"), lambda m: "gemm_lnb_kernel<bf16>"),
+    (re.compile(r"gemm_lnb_kernel<float, \d+>"), lambda m: "gemm_lnb_kernel<f32>"),
+    (re.compile(r"gemm_pipe_kernel<float,"), lambda m: "gemm_pipe_kernel<f32>"),
+    (re.compile(r"gemm_pipe_kernel(?:IDF16b|<bool _Accum)"), lambda m: "gemm_pipe_kernel<bf16>"),
+    (re.compile(r"gemm_wide_kernelIDF16bLi\d+ELb([01])E"), lambda m: "gemm_wide_kernel<bf16,%s>" % _LN[m.group(1)]),
+    (re.compile(r"gemm_wide_kernel<float, \d+, (true|false)>"), lambda m: "gemm_wide_kernel<f32,%s>" % _LN[m.group(1)]),
+    (re.compile(r"gemm_tn_kernel<float, \d+>"), lambda m: "gemm_tn_kernel<f32>"),
+    (re.compile(r"gemm_tn_kernelIDF16bLi\d+E"), lambda m: "gemm_tn_kernel<bf16>"),
+    (re.compile(r"gemm_kernelIDF16bDF16bLi(\d+)ELi\d+E"), lambda m: "gemm_kernel<bf16,bf16,%s>" % m.group(1)),
+    (re.compile(r"gemm_kernelIDF16bfLi(\d+)ELi\d+E"), lambda m: "gemm_kernel<bf16,f32,%s>" % m.group(1)),
+    (re.compile(r"gemm_kernel<float, float, (\d+), \d+>"), lambda m: "gemm_kernel<f32,f32,%s>" % m.group(1)),
 ]
 
 
@@ -40,7 +61,7 @@ def bench_name(kernel):
     for rx, fmt in RULES:
         m = rx.search(kernel)
         if m:
-            return fmt % m.groups() if m.groups() else fmt
+            return fmt(m)
     return None
 
 
@@ -77,6 +98,7 @@ def source_sha16(root):
 
 def main():
     workload, fetch_csv, write_csv, out_json = sys.argv[1:5]
+    sha = sys.argv[5] if len(sys.argv) > 5 else None      # recorded on the box by the stage that collected the counters
     fetch, write = read(fetch_csv, "FETCH_SIZE"), read(write_csv, "WRITE_SIZE")
     kernels = {}
     for name, (n, f_kib) in sorted(fetch.items()):
@@ -101,7 +123,7 @@ def main():
     doc.setdefault("sources", {})[workload] = [os.path.basename(fetch_csv), os.path.basename(write_csv)]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     # the counters must be parsed from the tree they were collected on (collect, then `copy`, before editing anything)
-    doc.setdefault("source_sha16", {})[workload] = source_sha16(root)
+    doc.setdefault("source_sha16", {})[workload] = sha or source_sha16(root)
     with open(out_json, "w") as f:
         json.dump(doc, f, indent=1, sort_keys=True)
     for k, v in kernels.items():
