@@ -9,15 +9,21 @@ semantics -- reduced grad = (sum over ranks) / world -- once per optimizer step:
 * ``arm(module)`` before the LAST backward that touches ``module``: per-parameter
   post-accumulate hooks count finished gradients; when a bucket's last gradient lands the bucket
   is gathered into its flat buffer (one multi-tensor copy) and its all-reduce launched on a side
-  stream, overlapping the rest of that backward;
+  stream, overlapping WHAT IS LEFT of that backward.  What is left is short for the main model: the
+  decode engine is one autograd node whose parameter gradients (151 MB of the model's 331 MB: the 12
+  decoder layers, embedding and generator) are batched products at the END of its backward sweep, so
+  their buckets go out when the sweep -- 17 of the generator phase's ~24 ms -- is already over; the
+  overlap window is the ~4 ms of encoder / bond-layer / style-generator backward that follows (their own
+  gradients land during it and are flushed by the final sync).  The window is not the decode sweep;
 * ``__call__(modules)`` after the last backward: reduces whatever was not armed / not
   flushed, waits for the side stream, divides by world and points every ``.grad`` at its slice of the
   reduced flat buffer (no scatter copy: the optimizer reads the slices in place).
 
 One process per GPU; backend "nccl" is RCCL on ROCm, "gloo" is used by the CPU tests.
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets default to 32 MiB so that each
-collective is large enough to be bandwidth- rather than latency-bound, while several are in
-flight behind the decode backward.
+collective is large enough to be bandwidth- rather than latency-bound; the ~10 buckets of the main
+model leave in a burst after the decode sweep (see above).  Measured single-rank cost of the path
+(identity reduction): tools/dp_overhead.py, profiles/r03_dp_single_rank.txt.
 """
 import torch
 import torch.distributed as dist

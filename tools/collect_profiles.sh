@@ -22,8 +22,9 @@ stage1)
   sha > gpurun_out/${tag}_sha_wgan.txt
   ;;
 stage2)
-  bash tools/pmc.sh FETCH_SIZE ${tag}_long_fetch --workload long || exit 1
-  bash tools/pmc.sh WRITE_SIZE ${tag}_long_write --workload long || exit 1
+  # sweeps launched eagerly: counter collection over this workload's replayed graphs (140-step sweeps) crashed rocprofv3
+  MSSR_DECODE_GRAPH=0 bash tools/pmc.sh FETCH_SIZE ${tag}_long_fetch --workload long || exit 1
+  MSSR_DECODE_GRAPH=0 bash tools/pmc.sh WRITE_SIZE ${tag}_long_write --workload long || exit 1
   sha > gpurun_out/${tag}_sha_long.txt
   ;;
 traffic)
@@ -50,6 +51,7 @@ stage3)
   timeout -k 10 200 python tools/sweep_bench.py 5 2>&1 | grep -v amdgpu > gpurun_out/${tag}_sweep.txt || exit 1
   timeout -k 10 200 python tools/graph_host_bench.py 2>&1 | grep -v amdgpu > gpurun_out/${tag}_graph_host.txt || exit 1
   bash tools/dphase_prof.sh ${tag} || exit 1
+  timeout -k 10 400 python tools/dp_overhead.py 2>&1 | grep -v amdgpu > gpurun_out/${tag}_dp_single_rank.txt || exit 1
   timeout -k 10 300 python bench.py > gpurun_out/bench_${tag}.json 2> gpurun_out/bench_${tag}.err || exit 1
   tail -1 gpurun_out/bench_${tag}.json
   ;;
@@ -64,7 +66,7 @@ copy)
   cp gpurun_out/workloads_${tag}.jsonl profiles/${tag}_workloads.jsonl
   cp gpurun_out/bench_${tag}.json profiles/${tag}_bench.json
   for f in chains attention skinny skinny_dma_on_off pipe_mid; do [ -f gpurun_out/${tag}_$f.log ] && cp gpurun_out/${tag}_$f.log profiles/${tag}_microbench_$f.txt; done
-  for f in host_time phase_wall sweep graph_host; do [ -f gpurun_out/${tag}_$f.txt ] && cp gpurun_out/${tag}_$f.txt profiles/${tag}_$f.txt; done
+  for f in host_time phase_wall sweep graph_host dp_single_rank; do [ -f gpurun_out/${tag}_$f.txt ] && cp gpurun_out/${tag}_$f.txt profiles/${tag}_$f.txt; done
   [ -f gpurun_out/dphase_${tag}.txt ] && cp gpurun_out/dphase_${tag}.txt profiles/${tag}_dphase_kernels.txt
   ;;
 *) echo "usage: collect_profiles.sh <tag> stage1|stage2|traffic|stage3|copy"; exit 2;;
