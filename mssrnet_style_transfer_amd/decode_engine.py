@@ -501,7 +501,7 @@ def _regime(spec, greedy=False):
     """What decides which rows / columns of the slabs a sweep writes (beyond their shapes, which key the pool)."""
     forced = None if greedy else getattr(spec, "forced", None)
     groups = getattr(spec, "groups", None)
-    return (bool(greedy), None if forced is None else tuple(forced.shape), int(spec.eval_rows), bool(spec.save),
+    return (bool(greedy), None if forced is None else tuple(forced.shape), int(spec.eval_rows), bool(spec.save), int(spec.bos),
             None if groups is None else tuple(tuple(int(v) for v in g) for g in groups),
             os.environ.get("MSSR_DECODE_LATE", "1"), os.environ.get("MSSR_DECODE_LATE_FWD", "1"))
 
