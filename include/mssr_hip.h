@@ -562,6 +562,11 @@ int mssr_decode_fwd(const mssr_decode_plan* plan, void* stream);
 int mssr_decode_bwd(const mssr_decode_plan* plan, void* stream);
 /* Number of recorded sweeps currently kept (diagnostics, tests).  No reference counterpart. */
 int mssr_decode_graphs(void);
+/* Replay on (default) / off for the whole process; returns the previous setting.  Off: every sweep is launched eagerly.
+ * A process that also drives a second stream (data-parallel ranks: the gradient all-reduce, parallel.GradSync) should
+ * turn it off -- measured on MI355X / ROCm 7.2: once a side stream has carried work, each replayed sweep runs ~2 ms
+ * longer on the GPU (43.2 -> 48.2 ms per WGAN step), while eagerly launched sweeps are unaffected (43.2 -> 43.7). */
+int mssr_decode_graphs_enable(int on);
 /* Recordings made since the process started (never decreases: a full cache evicts its least recently used sweep). */
 long mssr_decode_graphs_recorded(void);
 /* Gradient of the memory keys | values of a decode sweep, all layers in one launch: contracts the per-step slabs the

@@ -167,6 +167,7 @@ SIGNATURES = {
     "mssr_decode_bwd": ([POINTER(DecodePlan), _P], c_int),
     "mssr_decode_graphs": ([], c_int),
     "mssr_decode_graphs_recorded": ([], ctypes.c_long),
+    "mssr_decode_graphs_enable": ([_I], c_int),
     "mssr_debug_stamps": ([_P], None),
     "mssr_ctx_kv_grad": ([_P, _P, _L, _P, _L, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P], c_int),
 }

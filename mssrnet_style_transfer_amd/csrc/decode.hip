@@ -18,6 +18,7 @@
 #include <stdlib.h>
 #include <thread>
 #include <initializer_list>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1543,9 +1544,11 @@ static std::string sweep_key(const mssr_decode_plan* p, bool backward, hipStream
 }
 
 // true: the sweep was launched from a recorded graph (rc holds the result); false: the caller runs it eagerly
+static std::atomic<int> g_graph_switch{1};         // mssr_decode_graphs_enable (the MSSR_DECODE_GRAPH=0 veto stays)
+
 static bool run_sweep_graphed(const mssr_decode_plan* p, bool backward, hipStream_t stream, const char* who, int& rc) {
     static const bool enabled = [] { const char* e = getenv("MSSR_DECODE_GRAPH"); return !e || atoi(e) != 0; }();
-    if (!enabled || prof_active() || !p || !p->layers || p->n_layers <= 0 || p->n_chunks != 1) return false;
+    if (!enabled || !g_graph_switch.load(std::memory_order_relaxed) || prof_active() || !p || !p->layers || p->n_layers <= 0 || p->n_chunks != 1) return false;
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return false;
     int dev = 0;
@@ -1642,6 +1645,9 @@ static int sweep_graph_count() {
 using namespace mssr;
 
 extern "C" int mssr_decode_graphs(void) { return sweep_graph_count(); }
+extern "C" int mssr_decode_graphs_enable(int on) {
+    return g_graph_switch.exchange(on ? 1 : 0);
+}
 extern "C" long mssr_decode_graphs_recorded(void) {
     std::lock_guard<std::mutex> lock(g_graphs.mu);
     return g_graphs.recorded;

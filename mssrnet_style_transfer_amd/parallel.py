@@ -39,6 +39,12 @@ class GradSync:
         self.world = world_size if world_size is not None else (dist.get_world_size(group)
                                                                  if dist.is_initialized() else 1)
         self.active = self.world > 1 or (always and dist.is_initialized())
+        if self.active and torch.cuda.is_available():
+            # the reduction runs on a side stream, and replayed decode sweeps slow down (~2 ms each) in a process that
+            # drives a second stream (include/mssr_hip.h, mssr_decode_graphs_enable; profiles/r03_dp_single_rank.txt):
+            # data-parallel ranks launch their sweeps eagerly
+            from . import _lib as L
+            L.load().mssr_decode_graphs_enable(0)
         self.bucket_bytes = int(bucket_bytes)
         self.hook_min_numel = int(hook_min_numel)
         self._plans = {}        # id(module) -> list of buckets

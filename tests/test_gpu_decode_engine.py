@@ -411,6 +411,7 @@ def test_recorded_sweeps_replay_bit_identically(ops, dtype, monkeypatch):
     w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
     seeds = iter([1234, 1234, 1234, 1234, 99, 1234])
     monkeypatch.setattr(ops, "next_seed", lambda: next(seeds))
+    was_on = lib.mssr_decode_graphs_enable(1)         # a data-parallel test in this process may have turned replay off
     before = lib.mssr_decode_graphs_recorded()
     outs = []
     for _ in range(6):
@@ -423,6 +424,7 @@ def test_recorded_sweeps_replay_bit_identically(ops, dtype, monkeypatch):
         outs.append((probs.detach().cpu(), m.grad.cpu(), g.cpu()))
         del probs, m, g
     recorded = lib.mssr_decode_graphs_recorded() - before
+    lib.mssr_decode_graphs_enable(was_on)
     # buffers come from torch's caching allocator: the same sizes in the same order return the same blocks, so the
     # plans of calls 2.. match call 1's and both directions were recorded
     assert recorded >= 2, "no sweep was recorded (%d): the plans' buffers moved between identical calls" % recorded

@@ -47,7 +47,21 @@ def run(tag, mk, fill=None, launch=None):
     torch.cuda.synchronize()
     print("%-44s %.2f ms/step" % (tag, (time.perf_counter() - t0) / 15 * 1e3), flush=True)
 
-run("no sync", lambda: None)
+from mssrnet_style_transfer_amd import _lib as L
+run("no sync (sweeps replayed as hipGraphs)", lambda: None)
+L.load().mssr_decode_graphs_enable(0)
+run("no sync, sweeps launched eagerly", lambda: None)
+L.load().mssr_decode_graphs_enable(1)
+
+
+def replayed():
+    g = GradSync(1, always=True)
+    L.load().mssr_decode_graphs_enable(1)       # GradSync turns replay off; this variant shows why
+    return g
+
+
+run("full, sweeps replayed (the setting GradSync avoids)", replayed)
+# every variant below: as GradSync runs it -- sweeps launched eagerly
 run("full", lambda: GradSync(1, always=True))
 run("no fill", lambda: GradSync(1, always=True), fill=lambda self, b: None)
 run("no fill, no collective (side waits only)", lambda: GradSync(1, always=True), fill=lambda self, b: None, launch=launch_nocoll)
