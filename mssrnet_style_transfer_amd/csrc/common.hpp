@@ -117,6 +117,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return fmaxf(fmaxf(lane_read(v, 0), lane_read(v, 16)), fmaxf(lane_read(v, 32), lane_read(v, 48)));
 }
 
+// The per-call seed word of a replayed sweep (decode.hip), read through the CONSTANT address space: a uniform pointer
+// there becomes a scalar load (s_load_dwordx2, lgkmcnt).  As an ordinary global load it was a VECTOR load whose
+// `s_waitcnt vmcnt(0)` also waited for every LDS-DMA / fragment load the kernel had issued before it - the dropout
+// hashes, placed "under the loads", ran after them instead: +0.25 .. 0.6 us on every replayed kernel (0.9 ms per WGAN
+// step; rocprofv3, replayed vs eager sweeps).  The word is written by an earlier kernel of the stream and constant for
+// this one; kernel boundaries invalidate the scalar cache like they do for kernel arguments.
+__device__ __forceinline__ uint64_t seed_word(const uint64_t* p) {
+    typedef const __attribute__((address_space(4))) uint64_t* cptr;
+    return *(cptr)(uintptr_t)p;
+}
+
 // counter-based RNG for dropout: one 32-bit hash per element index.  32-bit arithmetic only (two multiplies:
 // the "lowbias32" finaliser over index ^ seed mix): the 64-bit splitmix it replaces cost ~400 cycles per wave
 // and element on CDNA (64-bit multiplies are sequences of quarter-rate 32-bit ones), which made the mask the

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_kernel(
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
     int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0,
     const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += *seed_base;
+    if (seed_base) seed += seed_word(seed_base);
     __shared__ float sc[4][AT_MAXK];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int bh_raw = blockIdx.x * 4 + wave;
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
     T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
     int bh_off, const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += *seed_base;
+    if (seed_base) seed += seed_word(seed_base);
     __shared__ float s_p[4][AT_MAXK];      // p, then ds
     __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p); then the gathered ds coefficients of later steps
     __shared__ float s_pd[4][AT_MAXK];     // dropped p; then the gathered pd coefficients of later steps
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
     int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0,
     const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += *seed_base;
+    if (seed_base) seed += seed_word(seed_base);
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
     T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
     int bh_off, const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += *seed_base;
+    if (seed_base) seed += seed_word(seed_base);
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -722,7 +722,7 @@ __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict
                                                              T* __restrict__ out, int rows, int d, int step, float s,
                                                              float p, uint64_t seed, int drop_row0,
                                                              const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += *seed_base;
+    if (seed_base) seed += seed_word(seed_base);
     const float sc = p > 0.f ? 1.0f / (1.0f - p) : 1.0f;
     const uint32_t thr = drop_thr16(p);
     const int64_t n = (int64_t)rows * d;

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void ln_bwd_dx_kernel(const T* __restrict__ dy
                                                         T* __restrict__ dx, T* __restrict__ dx2, int rows, int d,
                                                         float p, uint64_t seed, float extra, int row_off,
                                                         const uint64_t* __restrict__ seed_base = nullptr) {
-    if (seed_base) seed += *seed_base;          // replayed sweeps keep the call's seed in memory (decode.hip)
+    if (seed_base) seed += seed_word(seed_base);          // replayed sweeps keep the call's seed in memory (decode.hip)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;

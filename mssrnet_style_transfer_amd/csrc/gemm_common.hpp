@@ -54,7 +54,7 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, float p) 
     return keep16(seed, idx, drop_thr16(p));
 }
 // by-value seed + the word at seed_base (uniform: a scalar load)
-__device__ __forceinline__ uint64_t eff_seed(const GemmArgs& p, uint64_t s) { return p.seed_base ? s + *p.seed_base : s; }
+__device__ __forceinline__ uint64_t eff_seed(const GemmArgs& p, uint64_t s) { return p.seed_base ? s + seed_word(p.seed_base) : s; }
 // the seed_base every GemmArgs filled on this thread receives (gemm_fill_args); set by the decode engine while it
 // records a sweep, null otherwise
 extern thread_local const uint64_t* tl_seed_base;

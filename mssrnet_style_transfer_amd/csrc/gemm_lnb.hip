@@ -78,25 +78,30 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
                                              (__attribute__((address_space(3))) void*)(rW + g * 1024), 16, 0, 0);
         }
     }
+    // The small operands right BEHIND the DMA (ahead of it their ~7 scattered loads delay its issue), all of them
+    // unconditional and kept raw until after the wait: vector-memory loads return in order, and the first version
+    // converted the gate values here (an `s_waitcnt vmcnt(0)` of the compiler's), so the statistics / gamma loads were
+    // not even issued, and no dropout decision hashed, before the operand tiles had landed.
     const int fr = lane & 15, fc = lane >> 4;
     const int64_t arl = m0 + fr;
     const bool row_ok = arl < p.m;
     const int64_t ar = row_ok ? arl : p.m - 1;
     const int64_t arow = ar * p.a_rs;
-    // epilogue operands of the elements this thread finishes (e = tid + i*512: row e / LNB_TSN, col e % LNB_TSN)
     constexpr int EPT = (16 * LNB_TSN + LNB_THREADS - 1) / LNB_THREADS;
-    float gate[EPT];
+    bf16 graw[EPT];
     bool eok[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = threadIdx.x + i * LNB_THREADS;
         const int64_t erow = m0 + e / LNB_TSN, ecol = n0 + e % LNB_TSN;
         eok[i] = e < 16 * LNB_TSN && erow < p.m && ecol < p.n;
-        gate[i] = 1.f;
-        if (eok[i] && p.gate) gate[i] = to_f(reinterpret_cast<const bf16*>(p.gate)[erow * p.ldg + ecol]);
+        // an UNCONDITIONAL load from a clamped address (no gate: an element of dy, never used): a select between a
+        // constant and the loaded value would make the compiler wait for the load right here
+        const int64_t gr = erow < p.m ? erow : p.m - 1, gc = ecol < p.n ? ecol : p.n - 1;
+        const bf16* gp = p.gate ? reinterpret_cast<const bf16*>(p.gate) + gr * p.ldg + gc : DY + gr * p.a_rs;
+        graw[i] = *gp;
     }
     const float mu = p.lnb_mean[ar], rs = p.lnb_rstd[ar];
-    const uint64_t lnb_seed = eff_seed(p, p.lnb_seed);
     // gamma of this lane's k-chunks (half h: k = k0 + 32 h + 8 fc .. + 8)
     f32x4 g0[2], g1[2];
 #pragma unroll
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
         g0[h] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k);
         g1[h] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k + 4);
     }
+    const uint64_t lnb_seed = eff_seed(p, p.lnb_seed);
     // the dropout decisions depend on indices and the seed only: taken here, in the shadow of the loads
     const uint32_t thr = drop_thr16(p.lnb_p);
     uint32_t kp[2][4];
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
 #pragma unroll
         for (int w = 0; w < LNB_NW; ++w) v += red0[w * rstride + e];
         v *= p.alpha;
-        if (p.gate) v = gate[i] > 0.f ? v : 0.f;
+        if (p.gate) v = to_f(graw[i]) > 0.f ? v : 0.f;
         C[(m0 + rr) * p.ldc + n0 + cc] = from_f<TO>(v);
     }
 }
