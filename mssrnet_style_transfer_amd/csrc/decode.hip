@@ -377,7 +377,8 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, T* __restrict__ ctx, int64_t ctx_bs,
     int B, int H, int dh, int Lk, float scale, float p_drop_all, uint64_t seed, int drop_b0,
     const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += seed_word(seed_base);
+    uint64_t seed_w = 0;                       // the replayed sweep's seed word: requested now, added where it is used
+    if (seed_base) seed_w = seed_word(seed_base);
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -398,9 +399,12 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     load_chunk<T, AT_NL>(k0, kp, kv_ts, 0, r, RPL, Lk);
     load_chunk<T, AT_NL>(v0, vp, kv_ts, 0, r, RPL, Lk);
     const V qf = R::load(qp);
-    const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
+    // the key-padding byte of key `lane`: an unconditional load (no mask: a byte of the output row, unused), consumed after the
+    // chunk loads -- a select on the loaded value here would wait for it, i.e. for every K / V load issued before it
+    const uint8_t mk0 = *(mask ? mask + (int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1) : reinterpret_cast<const uint8_t*>(ctx + (int64_t)b * ctx_bs));
     // dropout decision of key `lane` (index + seed only): taken under the loads
     const uint32_t thr = drop_thr16(p_drop);
+    seed += seed_w;
     const bool keep0 = p_drop > 0.f ? keep16(seed, (uint64_t)bh * AT_MAXK + lane, thr) : true;
 
     auto scores = [&](const V (&kt)[AT_NL], int t0) {
@@ -481,7 +485,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
     T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
     int bh_off, const uint64_t* __restrict__ seed_base) {
-    if (seed_base) seed += seed_word(seed_base);
+    uint64_t seed_w = 0;
+    if (seed_base) seed_w = seed_word(seed_base);
     typedef Row16<T> R;
     typedef typename R::V V;
     constexpr int E = R::E;
@@ -511,8 +516,11 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     load_chunk<T, AT_NL>(v0, vp, kv_ts, 0, r, RPL, Lk);
     const V qf = R::load(qp);
     const V df = R::load(dcp);
-    const uint8_t mk0 = mask ? mask[(int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1)] : (uint8_t)0;
+    // the key-padding byte of key `lane`: an unconditional load (no mask: a byte of the output row, unused), consumed after the
+    // chunk loads -- a select on the loaded value here would wait for it, i.e. for every K / V load issued before it
+    const uint8_t mk0 = *(mask ? mask + (int64_t)b * mask_bs + (lane < Lk ? lane : Lk - 1) : reinterpret_cast<const uint8_t*>(dq + (int64_t)b * dq_bs));
     const uint32_t thr = drop_thr16(p_drop);         // dropout decision of key `lane`: taken under the loads
+    seed += seed_w;
     const bool keep0 = p_drop > 0.f ? keep16(seed, (uint64_t)(bh + bh_off) * AT_MAXK + lane, thr) : true;
     float ck0 = 0.f, cv0 = 0.f;
     if (gather) {
