@@ -43,10 +43,12 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     dbg_stamp(p, 0);
     const int64_t n0 = (int64_t)blockIdx.x * TSN, m0 = (int64_t)blockIdx.y * TSM;
     const int split = blockIdx.z;
-    const int64_t steps_total = p.k / 32;
-    const int64_t per = (steps_total + p.ksplit - 1) / p.ksplit;
-    const int64_t s_begin = split * per;
-    const int64_t s_end = (s_begin + per < steps_total) ? s_begin + per : steps_total;
+    // 32-bit arithmetic, and no division at all without K slabs: the 64-bit `/ p.ksplit` was a ~130-instruction software
+    // division on the scalar unit at the head of every launch (stamps: 0.5 us of index arithmetic before the first load)
+    const int steps_total = (int)(p.k >> 5);
+    const int per = p.ksplit == 1 ? steps_total : (int)((unsigned)(steps_total + p.ksplit - 1) / (unsigned)p.ksplit);
+    const int s_begin = split * per;
+    const int s_end = (s_begin + per < steps_total) ? s_begin + per : steps_total;
 
     const bf16* A = reinterpret_cast<const bf16*>(p.a);
     const bf16* W = reinterpret_cast<const bf16*>(p.b);
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_kernel(const GemmArgs 
     for (int f = 0; f < FM; ++f) sx[f] = sxx[f] = 0.f;
     // wave w owns k-steps s_begin + w, + 4, + 8 ... ; SK_GROUP of them in flight at a time  (contiguous quarters per
     // wave, so that one wave requests both halves of a 128-byte line back to back: WGAN step 51.0-51.6 ms against 50.8)
-    for (int64_t s0 = s_begin + wave; s0 < s_end; s0 += 4 * SK_GROUP) {
+    for (int s0 = s_begin + wave; s0 < s_end; s0 += 4 * SK_GROUP) {
         bf16x8 fa[SK_GROUP][FM], fb[SK_GROUP][FN];
 #pragma unroll
         for (int g = 0; g < SK_GROUP; ++g) {
@@ -226,10 +228,12 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
     dbg_stamp(p, 0);
     const int64_t n0 = (int64_t)blockIdx.x * TSN, m0 = (int64_t)blockIdx.y * TSM;
     const int split = blockIdx.z;
-    const int64_t steps_total = p.k / 32;
-    const int64_t per = (steps_total + p.ksplit - 1) / p.ksplit;
-    const int64_t s_begin = split * per;
-    const int64_t s_end = (s_begin + per < steps_total) ? s_begin + per : steps_total;
+    // 32-bit arithmetic, and no division at all without K slabs: the 64-bit `/ p.ksplit` was a ~130-instruction software
+    // division on the scalar unit at the head of every launch (stamps: 0.5 us of index arithmetic before the first load)
+    const int steps_total = (int)(p.k >> 5);
+    const int per = p.ksplit == 1 ? steps_total : (int)((unsigned)(steps_total + p.ksplit - 1) / (unsigned)p.ksplit);
+    const int s_begin = split * per;
+    const int s_end = (s_begin + per < steps_total) ? s_begin + per : steps_total;
     const int nb = (int)((s_end - s_begin + 1) / 2);            // 64-wide k-blocks of this block's range
     const int b_lo = wave * KBW;
 
