@@ -245,39 +245,41 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
     // DMA: lane L of an instruction fills slot L of an 8-row group: row L >> 3, physical 16-byte chunk L & 7, which holds
     // the logical chunk (L & 7) ^ swz(row)
     const int drow = lane >> 3, dpc = lane & 7;
-    const int64_t k_last = p.k - 8;
+    const int k_last = (int)p.k - 8;
     {
         const bf16* asrc[TSM / 8];
         const bf16* wsrc[TSN / 8];
         int achunk[TSM / 8], wchunk[TSN / 8];
+        // rows / columns as 32-bit integers (m, n < 2^31: the grid could not cover more), one 64-bit product per pointer
+        const int mi = (int)p.m, ni = (int)p.n, m0i = (int)m0, n0i = (int)n0;
 #pragma unroll
         for (int g = 0; g < TSM / 8; ++g) {
             const int r = g * 8 + drow;
-            const int64_t gr = m0 + r;
-            asrc[g] = A + (gr < p.m ? gr : p.m - 1) * p.a_rs;
+            const int gr = min(m0i + r, mi - 1);
+            asrc[g] = A + (int64_t)gr * p.a_rs;
             achunk[g] = (dpc ^ sk_swz(r)) * 8;
         }
 #pragma unroll
         for (int g = 0; g < TSN / 8; ++g) {
             const int r = g * 8 + drow;
-            const int64_t gn = n0 + r;
-            wsrc[g] = W + (gn < p.n ? gn : p.n - 1) * p.b_cs;
+            const int gn = min(n0i + r, ni - 1);
+            wsrc[g] = W + (int64_t)gn * p.b_cs;
             wchunk[g] = (dpc ^ sk_swz(r)) * 8;
         }
 #pragma unroll
         for (int bl = 0; bl < KBW; ++bl) {
             if (b_lo + bl >= nb) break;                          // wave-uniform: the last wave's range may be short
-            const int64_t k0 = (s_begin + 2 * (int64_t)(b_lo + bl)) * 32;
+            const int k0 = (s_begin + 2 * (b_lo + bl)) * 32;
 #pragma unroll
             for (int g = 0; g < TSN / 8; ++g) {
-                int64_t k = k0 + wchunk[g];
+                int k = k0 + wchunk[g];
                 k = k <= k_last ? k : k_last;    // second half past the end (odd count of k-steps): never multiplied
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[g] + k),
                                                  (__attribute__((address_space(3))) void*)(regW + (bl * TSN + g * 8) * 128), 16, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < TSM / 8; ++g) {
-                int64_t k = k0 + achunk[g];
+                int k = k0 + achunk[g];
                 k = k <= k_last ? k : k_last;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[g] + k),
                                                  (__attribute__((address_space(3))) void*)(regA + (bl * TSM + g * 8) * 128), 16, 0, 0);
