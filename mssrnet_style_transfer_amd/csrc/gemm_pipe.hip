@@ -135,13 +135,15 @@ __global__ __launch_bounds__(PP_THREADS, 2) void gemm_pipe_kernel(const PipeArgs
     const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
     const int64_t m0 = (int64_t)tm * BM, n0 = (int64_t)tn * BN;
 
-    const int64_t zo = blockIdx.z / p.batch_inner, zi = blockIdx.z % p.batch_inner;
+    // 32-bit divisions (batch <= 65535, K-steps < 2^31): each 64-bit one is a ~130-instruction software division
+    const int bi = (int)p.batch_inner;
+    const int64_t zo = (int)blockIdx.z / bi, zi = (int)blockIdx.z % bi;
     const bf16* A = reinterpret_cast<const bf16*>(p.a) + zo * p.a_bo + zi * p.a_bi;
     const bf16* B = reinterpret_cast<const bf16*>(p.b) + zo * p.b_bo + zi * p.b_bi;
 
     // K-steps of this slice
     const int64_t nk_all = (p.k + PP_BK - 1) / PP_BK;
-    const int64_t per = (nk_all + P.ksplit - 1) / P.ksplit;
+    const int64_t per = P.ksplit == 1 ? nk_all : (int64_t)(((unsigned)nk_all + (unsigned)P.ksplit - 1u) / (unsigned)P.ksplit);
     const int64_t t_begin = (int64_t)blockIdx.y * per;
     const int64_t t_end = t_begin + per < nk_all ? t_begin + per : nk_all;
 
