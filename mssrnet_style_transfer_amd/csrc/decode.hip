@@ -735,12 +735,13 @@ __global__ __launch_bounds__(256) void embed_epilogue_kernel(const T* __restrict
     const uint32_t thr = drop_thr16(p);
     const int64_t n = (int64_t)rows * d;
     for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
-        const int c = (int)(i % d);
+        const uint32_t row = (uint32_t)i / (uint32_t)d;      // rows * d < 2^31 (a step's [B, d] slab): 32-bit division
+        const int c = (int)((uint32_t)i - row * (uint32_t)d);
         float v[4], pp[4], o[4];
         V4<T>::load(e + i, v);
         V4<float>::load(pe + (int64_t)step * d + c, pp);
         uint32_t kp[2] = {3u, 3u};          // i is a multiple of 4: two whole decision pairs
-        const bool drop = p > 0.f && (int)(i / d) >= drop_row0;
+        const bool drop = p > 0.f && (int)row >= drop_row0;
         if (drop) {
             kp[0] = keep16_pair(seed, (uint64_t)i >> 1, thr);
             kp[1] = keep16_pair(seed, ((uint64_t)i >> 1) + 1, thr);

@@ -106,8 +106,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     // p.ksplit > 1: blockIdx.z = batch * ksplit + K slice; the slices add into the pre-set fp32 output with atomics
-    const int64_t zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
-    const int64_t zo = zb / p.batch_inner, zi = zb % p.batch_inner;
+    // 32-bit divisions (gridDim.z <= 65535; a 64-bit one is a ~130-instruction software routine at the head of the launch)
+    const int zbi = (int)blockIdx.z / p.ksplit;
+    const int64_t zb = zbi, zs = (int)blockIdx.z - zbi * p.ksplit;
+    const int zoi = zbi / (int)p.batch_inner;
+    const int64_t zo = zoi, zi = zbi - zoi * (int)p.batch_inner;
     const TI* A = reinterpret_cast<const TI*>(p.a) + zo * p.a_bo + zi * p.a_bi;
     const TI* B = reinterpret_cast<const TI*>(p.b) + zo * p.b_bo + zi * p.b_bi;
     const int64_t coff = zo * p.c_bo + zi * p.c_bi;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_kernel(const GemmArgs p) {
     TileLoader<TI, BM> la;
     TileLoader<TI, BN> lb;
     const int64_t nk_all = (p.k + BK - 1) / BK;
-    const int64_t per = (nk_all + p.ksplit - 1) / p.ksplit;
+    const int64_t per = p.ksplit == 1 ? nk_all : (int64_t)(((unsigned)nk_all + (unsigned)p.ksplit - 1u) / (unsigned)p.ksplit);
     const int64_t t0 = zs * per, nk = t0 + per < nk_all ? t0 + per : nk_all;
     la.fetch(A, m0, t0 * BK, p.m, p.k, p.a_rs, p.a_cs, a_km, p.a_vec);
     lb.fetch(B, n0, t0 * BK, p.n, p.k, p.b_cs, p.b_rs, b_km, p.b_vec);   // rows of the B image are n

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_reduce_kernel(const GemmArgs 
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
         float v = 0.f;
         for (int s = 0; s < p.ksplit; ++s) v += p.partial[(int64_t)s * total + i];
-        const int64_t row = i / p.n, col = i - row * p.n;
+        const int64_t row = (int64_t)((uint32_t)i / (uint32_t)p.n), col = i - row * p.n;      // m * n < 2^31 (m <= 1024 here)
         epilogue_store<bf16, TO>(p, v, row, col, p.bias ? p.bias[col] : 0.f, C, R, G, 0);
     }
 }

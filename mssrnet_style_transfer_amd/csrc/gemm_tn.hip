@@ -99,8 +99,10 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs p) {
     __shared__ __attribute__((aligned(16))) short Bs[TN_BK * LD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int64_t zb = blockIdx.z / p.ksplit, zs = blockIdx.z % p.ksplit;
-    const int64_t zo = zb / p.batch_inner, zi = zb % p.batch_inner;
+    const int zbi = (int)blockIdx.z / p.ksplit;                       // 32-bit divisions (gridDim.z <= 65535)
+    const int64_t zs = (int)blockIdx.z - zbi * p.ksplit;
+    const int zoi = zbi / (int)p.batch_inner;
+    const int64_t zo = zoi, zi = zbi - zoi * (int)p.batch_inner;
     const bf16* A = p.a + zo * p.a_bo + zi * p.a_bi;
     const bf16* B = p.b + zo * p.b_bo + zi * p.b_bi;
     const int64_t m0 = (int64_t)blockIdx.y * BT, n0 = (int64_t)blockIdx.x * BT;
@@ -112,7 +114,8 @@ __global__ __launch_bounds__(TN_THREADS) void gemm_tn_kernel(const TnArgs p) {
         for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     TnLoader<BT> la, lb;
     const int64_t nk_all = (p.k + TN_BK - 1) / TN_BK;
-    const int64_t per = (nk_all + p.ksplit - 1) / p.ksplit;            // k-tiles of this slice
+    const int64_t per = p.ksplit == 1 ? nk_all                        // k-tiles of this slice
+                                      : (int64_t)(((unsigned)nk_all + (unsigned)p.ksplit - 1u) / (unsigned)p.ksplit);
     const int64_t t_begin = zs * per, nk = t_begin + per < nk_all ? t_begin + per : nk_all;
     // segmented k (seg_len >= TN_BK, so a tile crosses at most one segment boundary): uniform 32-bit arithmetic per tile
     const int64_t jump = p.seg_stride - p.seg_len;
