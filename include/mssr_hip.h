@@ -500,9 +500,10 @@ typedef struct {
     void* dactD;                  /* [n_layers][7][T][B, d]  dn1|d_so|dn2|d_cq|d_co|dn3|d_f2 */
     void* dactF;                  /* [n_layers][T][B, ff]    d_f1 */
     void* dctx;                   /* [n_layers][2][T][B, d] gradients of the self / context attention outputs */
-    float* ds_self;               /* [n_layers][2][T][B*heads][T]: per step s, score gradients ds_s[t] and dropped
-                                   * probabilities pd_s[t] (t <= s) of the self attention; key / value gradients
-                                   * are gathered from these (dK[t] = sum_{s>=t} ds_s[t] q_s, ...) */
+    float* ds_self;               /* [n_layers][B*heads][T keys][T steps][2]: pairs (score gradient ds_s[t], dropped
+                                   * probability pd_s[t]), t <= s, of the self attention, key-major: key / value
+                                   * gradients are gathered from these (dK[t] = sum_{s>=t} ds_s[t] q_s, ...), and
+                                   * the coefficients of one key over the steps are contiguous */
     float* ds_ctx;                /* [n_layers][2][T][B*heads][Ls]: the same for the context attention; the caller
                                    * contracts them over the steps: dL/d mem K = sum_s ds_s (x) qc_s,
                                    * dL/d mem V = sum_s pd_s (x) dctx_s */

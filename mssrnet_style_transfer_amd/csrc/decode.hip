@@ -113,10 +113,16 @@ __global__ __launch_bounds__(256) void attn_step_fwd_kernel(
 // key/value gradients are GATHERED from those slabs, never accumulated in memory --
 //   dK[t] = sum_{s >= t} ds_s[t] q_s ,  dV[t] = sum_{s >= t} pd_s[t] dctx_s .
 // Self attention (gather != 0): row t = s of K/V is final once step s runs (later steps ran before it
-// in the reverse sweep), so this launch also forms dK[s], dV[s] from the slabs of steps s .. T-1
-// (stride slab_ss between steps), the q rows of the packed cache (stride q_ss) and the saved dctx rows
-// (stride dctx_ss), and writes them into the dqkv slot of step s.  Context attention: the caller
-// contracts the slabs over all steps at the end (one batched product per layer).
+// in the reverse sweep), so this launch also forms dK[s], dV[s] from the entries of steps s .. T-1,
+// the q rows of the packed cache (stride q_ss) and the saved dctx rows (stride dctx_ss), and writes
+// them into the dqkv slot of step s.  For the gather the self-attention slab is KEY-major, pairs
+// sl[bh][t][s] = {ds_s[t], pd_s[t]} (ds_out = its base, slab_bhs = T * T pairs, pd_out / slab_ss unused):
+// a step writes one pair per key (8-byte stores, T pairs apart) and reads the coefficients of its own key
+// row over the later steps as ONE contiguous run.  (Step-major rows, the layout until round 3, made every
+// coefficient a lone 4-byte read of its own cache line: at 140 steps 2 x 140 lines per (sentence, head)
+// and launch, up to 73 MB of line traffic beside the 143 MB of q / dctx rows.)  Context attention
+// (gather == 0): rows ds_out / pd_out [Lk] of this step; the caller contracts the slabs over all steps
+// at the end (one batched product per layer).
 template <typename T>
 __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
@@ -138,8 +144,12 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
     const T* kp = k + (int64_t)b * kv_bs + h * dh;
     const T* vp = v + (int64_t)b * kv_bs + h * dh;
     const T* dcp = dctx + (int64_t)b * dctx_bs + h * dh;
-    float* dso = ds_out + (int64_t)bh * slab_bhs;
-    float* pdo = pd_out + (int64_t)bh * slab_bhs;
+    // context attention (gather == 0): rows ds_out / pd_out [Lk] of this step.  Self attention: ONE slab of pairs
+    // {ds_s[t], pd_s[t]} with the (sentence, head) index innermost, sl[(t * n_steps + s) * slab_bhs]: the waves of a
+    // block write / read neighbouring pairs of the same (key, step) sector
+    float* dso = gather ? nullptr : ds_out + (int64_t)bh * slab_bhs;
+    float* pdo = gather ? nullptr : pd_out + (int64_t)bh * slab_bhs;
+    float2* sl = gather ? reinterpret_cast<float2*>(ds_out) + bh : nullptr;
     float* s = s_p[wave];
     float* dpv = s_dp[wave];
     float* pdv = s_pd[wave];
@@ -194,7 +204,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
         s[t] = p;
         dpv[t] = dp;
         pdv[t] = p * m;
-        if (active) pdo[t] = p * m;
+        if (active && !gather) pdo[t] = p * m;
         r += p * dp;
     }
     r = wave_sum(r);
@@ -202,15 +212,19 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
         float ds = s[t] * (dpv[t] - r) * scale;
         if (mask && mask[(int64_t)b * mask_bs + t]) ds = 0.f;     // masked_fill: no gradient to the score
         s[t] = ds;
-        if (active) dso[t] = ds;
+        if (active) {
+            if (gather) sl[((int64_t)t * n_steps + step) * slab_bhs] = make_float2(ds, pdv[t]);
+            else dso[t] = ds;
+        }
     }
     __syncthreads();
     const float pd_own = gather ? pdv[step] : 0.f;
     __syncthreads();
-    // coefficients of row `step` in the slabs of steps step+1 .. T-1 (slab of step s' sits (s'-step)*slab_ss on)
+    // coefficients of key row `step` at the steps step+1 .. T-1
     for (int i = lane; i < n_later; i += 64) {
-        dpv[i] = dso[(int64_t)(i + 1) * slab_ss + step];
-        pdv[i] = pdo[(int64_t)(i + 1) * slab_ss + step];
+        const float2 cf = sl[((int64_t)step * n_steps + step + 1 + i) * slab_bhs];
+        dpv[i] = cf.x;
+        pdv[i] = cf.y;
     }
     __syncthreads();
     if (!active) return;
@@ -255,10 +269,13 @@ __global__ __launch_bounds__(256) void attn_step_bwd_kernel(
 // dh / E lanes cover one key / value row (E = elements per 16 bytes) and a wave covers 64 / LPR rows per load
 // instruction; AT_NL instructions (a "chunk" of rows) are in flight together.  Every address of the first chunk
 // of K, of V (and, in the backward, of the later steps' q / dctx rows and slab coefficients) is known at kernel
-// start, so for up to 64 bf16 rows the whole kernel exposes ONE memory round trip; the one-row-per-lane kernels
+// start, so for up to 32 bf16 rows the whole kernel exposes ONE memory round trip; the one-row-per-lane kernels
 // above issue Lk dependent 2-byte loads in their lane <-> feature phases (measured at 140 keys: 55 / 140 us).
-// AT_NL load instructions per chunk: template parameter, 4 when every operand has at most 4 x (rows per
-// instruction) rows (Yelp lengths: <= 28 keys / steps at 8 rows per instruction), else 8
+// AT_NL load instructions per chunk (template parameter): 4 -- Yelp lengths (<= 28 keys / steps) fit one chunk at
+// 8 rows per instruction; longer operands loop over chunks in the forward (8-row-load chunks cost registers, 118
+// against 71 VGPRs, and at 768 sentences x 128 words the occupancy is worth more: 532 -> 524 ms per step) and
+// take the streaming kernel below in the backward (the 8-row-load backward instance remains for strides beyond
+// that kernel's 32-bit offsets).
 
 template <typename T> struct Row16;
 template <> struct Row16<bf16> {
@@ -290,6 +307,22 @@ __device__ __forceinline__ float dot16(const typename Row16<T>::V& a, const type
 #pragma unroll
     for (int e = 0; e < Row16<T>::E; ++e) r += (float)a[e] * (float)b[e];
     return r;
+}
+
+// the same product on the packed-bf16 dot instruction (v_dot2c_f32_bf16: exact products, fp32 accumulation; no
+// unpacked copies of the operands in registers)
+template <typename T>
+__device__ __forceinline__ float dot16_packed(const typename Row16<T>::V& a, const typename Row16<T>::V& b) {
+    if constexpr (sizeof(T) == 2) {
+        float r = 0.f;
+        r = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 0, 1), __builtin_shufflevector(b, b, 0, 1), r, false);
+        r = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 2, 3), __builtin_shufflevector(b, b, 2, 3), r, false);
+        r = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 4, 5), __builtin_shufflevector(b, b, 4, 5), r, false);
+        r = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(a, a, 6, 7), __builtin_shufflevector(b, b, 6, 7), r, false);
+        return r;
+    } else {
+        return dot16<T>(a, b);
+    }
 }
 
 // sum over the 2^LS adjacent lanes that hold one row (every lane of the group gets the total): DPP moves, no LDS
@@ -383,7 +416,8 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
     typedef typename R::V V;
     constexpr int E = R::E;
     __shared__ float sc[4][AT_MAXK];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index through the scalar unit: (sentence, head) and every base address derived from it live in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int bh_raw = blockIdx.x * 4 + wave;
     const bool active = bh_raw < B * H;
     const int bh = active ? bh_raw : B * H - 1;
@@ -493,7 +527,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     __shared__ float s_p[4][AT_MAXK];      // scores, p, then ds
     __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p); then the ds coefficients of steps step .. T-1
     __shared__ float s_pd[4][AT_MAXK];     // dropped p; then the pd coefficients of steps step .. T-1
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index through the scalar unit: (sentence, head) and every base address derived from it live in SGPRs
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int bh_raw = blockIdx.x * 4 + wave;
     const bool active = bh_raw < B * H;
     const int bh = active ? bh_raw : B * H - 1;
@@ -504,8 +539,12 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
     const T* kp = k + (int64_t)b * kv_bs + h * dh + c * E;
     const T* vp = v + (int64_t)b * kv_bs + h * dh + c * E;
     const T* dcp = dctx + (int64_t)b * dctx_bs + h * dh + c * E;
-    float* dso = ds_out + (int64_t)bh * slab_bhs;
-    float* pdo = pd_out + (int64_t)bh * slab_bhs;
+    // context attention (gather == 0): rows ds_out / pd_out [Lk] of this step.  Self attention: ONE slab of pairs
+    // {ds_s[t], pd_s[t]} with the (sentence, head) index innermost, sl[(t * n_steps + s) * slab_bhs]: the waves of a
+    // block write / read neighbouring pairs of the same (key, step) sector
+    float* dso = gather ? nullptr : ds_out + (int64_t)bh * slab_bhs;
+    float* pdo = gather ? nullptr : pd_out + (int64_t)bh * slab_bhs;
+    float2* sl = gather ? reinterpret_cast<float2*>(ds_out) + bh : nullptr;
     float* s = s_p[wave];
     float* dpv = s_dp[wave];
     float* pdv = s_pd[wave];
@@ -527,9 +566,10 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         load_chunk<T, AT_NL>(q0, qp, q_ss, 0, r, RPL, n_rows);
         load_chunk<T, AT_NL>(d0, dcp, dctx_ss, 0, r, RPL, n_rows);
         const int i = lane >= 1 && lane < n_rows ? lane : (n_rows > 1 ? 1 : 0);
-        if (n_rows > 1) {                       // slabs of the later steps exist (written by earlier launches)
-            ck0 = dso[(int64_t)i * slab_ss + step];
-            cv0 = pdo[(int64_t)i * slab_ss + step];
+        if (n_rows > 1) {                       // entries of the later steps exist (written by earlier launches)
+            const float2 cf = sl[((int64_t)step * n_steps + step + i) * slab_bhs];
+            ck0 = cf.x;
+            cv0 = cf.y;
         }
     }
 
@@ -581,7 +621,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         s[t] = p;
         dpv[t] = dp;
         pdv[t] = p * m;
-        if (active) pdo[t] = p * m;
+        if (active && !gather) pdo[t] = p * m;
         rr += p * dp;
     }
     rr = wave_sum(rr);
@@ -590,7 +630,10 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         const bool masked = mask && (t < 64 ? mk0 : mask[(int64_t)b * mask_bs + t]);
         if (masked) ds = 0.f;                    // masked_fill: no gradient to the score
         s[t] = ds;
-        if (active) dso[t] = ds;
+        if (active) {
+            if (gather) sl[((int64_t)t * n_steps + step) * slab_bhs] = make_float2(ds, pdv[t]);
+            else dso[t] = ds;
+        }
     }
     wave_lds_sync();
     const float ds_own = gather ? s[step] : 0.f;
@@ -605,8 +648,9 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
             pdv[lane] = cv0;
         }
         for (int i = lane + 64; i < n_rows; i += 64) {
-            dpv[i] = dso[(int64_t)i * slab_ss + step];
-            pdv[i] = pdo[(int64_t)i * slab_ss + step];
+            const float2 cf = sl[((int64_t)step * n_steps + step + i) * slab_bhs];
+            dpv[i] = cf.x;
+            pdv[i] = cf.y;
         }
     }
     wave_lds_sync();
@@ -662,6 +706,277 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
         load_chunk<T, AT_NL>(qt, qp, q_ss, t0, r, RPL, n_rows);
         load_chunk<T, AT_NL>(dt, dcp, dctx_ss, t0, r, RPL, n_rows);
         gacc(qt, dt, t0);
+    }
+    if constexpr (LS == 3 && E == 8) {
+        const float ok = group8_transpose_sum(gk, lane), ov = group8_transpose_sum(gv, lane);
+        if (active) {
+            const int64_t o = (int64_t)b * out_bs + h * dh + c * E + group8_elem(lane);
+            dk_out[o] = from_f<T>(ok);
+            dv_out[o] = from_f<T>(ov);
+        }
+    } else {
+        cross_group_sum<LS, E>(gk);
+        cross_group_sum<LS, E>(gv);
+        if (active && r == 0) {
+            R::store(dk_out + (int64_t)b * out_bs + h * dh + c * E, gk);
+            R::store(dv_out + (int64_t)b * out_bs + h * dh + c * E, gv);
+        }
+    }
+}
+
+// Backward for operands of more than one chunk (long sentences).  The kernel above reads K twice when the keys
+// do not fit its first chunk (scores, then dq = sum_t ds_t K[t] once the softmax is known) and holds four operand
+// chunks in registers (231 VGPRs with 8-row-load chunks: 2 waves per SIMD).  Here K and V stream through ONCE: with
+// e_t = exp(a_t - m) against a running maximum m (rescaled when it moves, per row group -- no cross-lane traffic
+// inside the loop),
+//     dq = scale / L * ( sum_t e_t dp_t K[t]  -  rr * sum_t e_t K[t] ),   L = sum_t e_t,  rr = sum_t e_t dp_t / L,
+// so both sums accumulate in the pass that produces the scores; the row groups' partial results are merged once at
+// the end (split-softmax combine).  The score gradients / dropped probabilities of the slabs are finished from the
+// raw scores kept in LDS.  No operand rows are held across phases, wave-uniform base addresses sit in SGPRs (lanes
+// carry 32-bit byte offsets) and the bf16 dot products use the packed instruction: 97 VGPRs, 5 waves per SIMD, all
+// waves of a 512-sentence launch resident at once.  Measured on --workload long (bs256, 128 words; ms per WGAN
+// step): 560.1 with the kernel above, 545.8 with this one; variants that request the next chunk while the current
+// one is worked on need the registers of a second chunk and lose more to occupancy than they gain (4-row-load
+// chunks, double-buffered, 152 VGPRs: 550.3; 2-row-load chunks, 98 VGPRs: 548.8) -- thread-level parallelism
+// hides the latency here, not software pipelining.
+template <int LS>
+__device__ __forceinline__ float cross_group_max(float v) {
+#define MSSR_XMAX(O) \
+    if constexpr ((1 << LS) <= O) v = fmaxf(v, xor_get<O>(v));
+    MSSR_XMAX(1)
+    MSSR_XMAX(2)
+    MSSR_XMAX(4)
+    MSSR_XMAX(8)
+    MSSR_XMAX(16)
+    MSSR_XMAX(32)
+#undef MSSR_XMAX
+    return v;
+}
+
+template <typename T, int LS, int AT_NL>
+__global__ __launch_bounds__(256) void attn_step_bwd_stream_kernel(
+    const T* __restrict__ q, int64_t q_bs, const T* __restrict__ k, const T* __restrict__ v, int64_t kv_bs,
+    int64_t kv_ts, const uint8_t* __restrict__ mask, int64_t mask_bs, const T* __restrict__ dctx, int64_t dctx_bs,
+    T* __restrict__ dq, int64_t dq_bs, float* __restrict__ ds_out, float* __restrict__ pd_out, int64_t slab_bhs,
+    int gather, int step, int n_steps, int64_t slab_ss, int64_t q_ss, int64_t dctx_ss, T* __restrict__ dk_out,
+    T* __restrict__ dv_out, int64_t out_bs, int B, int H, int dh, int Lk, float scale, float p_drop, uint64_t seed,
+    int bh_off, const uint64_t* __restrict__ seed_base) {
+    uint64_t seed_w = 0;
+    if (seed_base) seed_w = seed_word(seed_base);
+    typedef Row16<T> R;
+    typedef typename R::V V;
+    constexpr int E = R::E;
+    __shared__ float s_p[4][AT_MAXK];      // masked scores, then ds
+    __shared__ float s_dp[4][AT_MAXK];     // d(loss)/d(p) after dropout; then the ds coefficients of steps step .. T-1
+    __shared__ float s_pd[4][AT_MAXK];     // dropout multiplier, then dropped p; then the pd coefficients
+    // wave-uniform values through the scalar unit: base addresses live in SGPRs, lanes carry 32-bit byte offsets
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int bh_raw = blockIdx.x * 4 + wave;
+    const bool active = bh_raw < B * H;
+    const int bh = active ? bh_raw : B * H - 1;
+    const int b = bh / H, h = bh % H;
+    constexpr int LPR = 1 << LS, RPL = 64 >> LS, RC = AT_NL * RPL;
+    const int c = lane & (LPR - 1), r = lane >> LS;
+    const char* qp = reinterpret_cast<const char*>(q + (int64_t)b * q_bs + h * dh);
+    const char* kp = reinterpret_cast<const char*>(k + (int64_t)b * kv_bs + h * dh);
+    const char* vp = reinterpret_cast<const char*>(v + (int64_t)b * kv_bs + h * dh);
+    const char* dcp = reinterpret_cast<const char*>(dctx + (int64_t)b * dctx_bs + h * dh);
+    const uint32_t co = (uint32_t)(c * E * sizeof(T));                       // this lane's 16-byte column group
+    const uint32_t kv_tsb = (uint32_t)(kv_ts * sizeof(T)), q_ssb = (uint32_t)(q_ss * sizeof(T)),
+                   dctx_ssb = (uint32_t)(dctx_ss * sizeof(T));
+    auto load_rows = [&](V (&dst)[AT_NL], const char* base, uint32_t rsb, int t0, int n) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            int t = t0 + i * RPL + r;
+            t = t < n ? t : n - 1;
+            dst[i] = *reinterpret_cast<const V*>(base + ((uint32_t)t * rsb + co));
+        }
+    };
+    const uint8_t* mrow = mask ? mask + (int64_t)b * mask_bs : nullptr;
+    // context attention (gather == 0): rows ds_out / pd_out [Lk] of this step.  Self attention: ONE slab of pairs
+    // {ds_s[t], pd_s[t]} with the (sentence, head) index innermost, sl[(t * n_steps + s) * slab_bhs]: the waves of a
+    // block write / read neighbouring pairs of the same (key, step) sector
+    float* dso = gather ? nullptr : ds_out + (int64_t)bh * slab_bhs;
+    float* pdo = gather ? nullptr : pd_out + (int64_t)bh * slab_bhs;
+    float2* sl = gather ? reinterpret_cast<float2*>(ds_out) + bh : nullptr;
+    float* s = s_p[wave];
+    float* dpv = s_dp[wave];
+    float* pdv = s_pd[wave];
+    const int n_rows = gather ? n_steps - step : 0;      // this step and the later ones
+
+    V kc[AT_NL], vc[AT_NL];
+    uint8_t mc[AT_NL];
+    auto load_kv = [&](V (&kk)[AT_NL], V (&vv)[AT_NL], uint8_t (&mm)[AT_NL], int t0) {
+        load_rows(kk, kp, kv_tsb, t0, Lk);
+        load_rows(vv, vp, kv_tsb, t0, Lk);
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) mm[i] = 0;
+        if (mrow) {
+#pragma unroll
+            for (int i = 0; i < AT_NL; ++i) {
+                const int t = t0 + i * RPL + r;
+                mm[i] = mrow[(uint32_t)(t < Lk ? t : Lk - 1)];
+            }
+        }
+    };
+    load_kv(kc, vc, mc, 0);
+    const V qf = *reinterpret_cast<const V*>(qp + co);
+    const V df = *reinterpret_cast<const V*>(dcp + co);
+    float ck0 = 0.f, cv0 = 0.f;
+    if (gather && n_rows > 1) {                 // slabs of the later steps exist (written by earlier launches)
+        const int i = lane >= 1 && lane < n_rows ? lane : 1;
+        const float2 cf = sl[((int64_t)step * n_steps + step + i) * slab_bhs];
+        ck0 = cf.x;
+        cv0 = cf.y;
+    }
+    const uint32_t thr = drop_thr16(p_drop);
+    seed += seed_w;
+    const float keep_scale = p_drop > 0.f ? 1.0f / (1.0f - p_drop) : 1.0f;
+    const uint64_t hrow = (uint64_t)(bh + bh_off) * AT_MAXK;
+
+    float m = -1e30f, l = 0.f, rn = 0.f, A[E], Bv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) A[e] = Bv[e] = 0.f;
+    for (int t0 = 0;;) {
+        float a[AT_NL], g[AT_NL];
+        float cm = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            a[i] = -INFINITY;
+            g[i] = 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= Lk) break;                  // uniform: the rest of the chunk is past the last key
+            const int t = t0 + i * RPL + r;
+            float av = group_sum<LS>(dot16_packed<T>(kc[i], qf)) * scale;
+            float gv = group_sum<LS>(dot16_packed<T>(vc[i], df));
+            float mul = 1.0f;
+            if (p_drop > 0.f) mul = keep16(seed, hrow + t, thr) ? keep_scale : 0.f;
+            if (mc[i]) av = -1e18f;
+            if (t >= Lk) av = -INFINITY;
+            gv *= mul;
+            if (c == 0 && t < Lk) {
+                s[t] = av;
+                dpv[t] = gv;
+                pdv[t] = mul;
+            }
+            a[i] = av;
+            g[i] = gv;
+            cm = fmaxf(cm, av);
+        }
+        const float m_new = fmaxf(m, cm);
+        const float alpha = expf(m - m_new);
+        m = m_new;
+        l *= alpha;
+        rn *= alpha;
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            A[e] *= alpha;
+            Bv[e] *= alpha;
+        }
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= Lk) break;
+            const float ex = expf(a[i] - m);
+            l += ex;
+            rn += ex * g[i];
+            const float ek = mc[i] ? 0.f : ex;          // masked_fill: no gradient to a masked score
+            const float wk = ek * g[i];
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const float kf = (float)kc[i][e];
+                A[e] += wk * kf;
+                Bv[e] += ek * kf;
+            }
+        }
+        t0 += RC;
+        if (t0 >= Lk) break;
+        load_kv(kc, vc, mc, t0);
+    }
+    // the later steps' q / dctx rows: first chunk requested before the merge and the slab arithmetic
+    V qa[AT_NL], da[AT_NL];
+    if (gather) {
+        load_rows(qa, qp, q_ssb, 0, n_rows);
+        load_rows(da, dcp, dctx_ssb, 0, n_rows);
+    }
+    // merge the row groups
+    const float M = cross_group_max<LS>(m);
+    const float f = expf(m - M);
+    float lr[2] = {l * f, rn * f};
+    cross_group_sum<LS, 2>(lr);
+    const float inv = 1.0f / lr[0];
+    const float rr = lr[1] * inv;
+    {
+        float o[E];
+        const float w = f * inv * scale;
+#pragma unroll
+        for (int e = 0; e < E; ++e) o[e] = (A[e] - rr * Bv[e]) * w;
+        if constexpr (LS == 3 && E == 8) {
+            const float x = group8_transpose_sum(o, lane);
+            if (active) dq[(int64_t)b * dq_bs + h * dh + c * E + group8_elem(lane)] = from_f<T>(x);
+        } else {
+            cross_group_sum<LS, E>(o);
+            if (active && r == 0) R::store(dq + (int64_t)b * dq_bs + h * dh + c * E, o);
+        }
+    }
+    wave_lds_sync();
+    for (int t = lane; t < Lk; t += 64) {
+        const float av = s[t];
+        const float p = expf(av - M) * inv;
+        const float pm = p * pdv[t];
+        float ds = p * (dpv[t] - rr) * scale;
+        if (av == -1e18f) ds = 0.f;              // masked_fill: no gradient to the score
+        s[t] = ds;
+        pdv[t] = pm;
+        if (active) {
+            if (gather) {
+                sl[((int64_t)t * n_steps + step) * slab_bhs] = make_float2(ds, pm);
+            } else {
+                dso[t] = ds;
+                pdo[t] = pm;
+            }
+        }
+    }
+    if (!gather) return;
+    wave_lds_sync();
+    const float ds_own = s[step];
+    const float pd_own = pdv[step];
+    wave_lds_sync();
+    if (lane == 0) {                             // coefficient of row `step` in the slab of step step + i
+        dpv[0] = ds_own;
+        pdv[0] = pd_own;
+    } else if (lane < n_rows) {
+        dpv[lane] = ck0;
+        pdv[lane] = cv0;
+    }
+    for (int i = lane + 64; i < n_rows; i += 64) {
+        const float2 cf = sl[((int64_t)step * n_steps + step + i) * slab_bhs];
+        dpv[i] = cf.x;
+        pdv[i] = cf.y;
+    }
+    wave_lds_sync();
+    // dK[step] = sum_i ds_{step+i}[step] q_{step+i} ; dV[step] = sum_i pd_{step+i}[step] dctx_{step+i}
+    float gk[E], gv[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) gk[e] = gv[e] = 0.f;
+    for (int t0 = 0;;) {
+#pragma unroll
+        for (int i = 0; i < AT_NL; ++i) {
+            if (t0 + i * RPL >= n_rows) break;
+            const int t = t0 + i * RPL + r;
+            const float wk = t < n_rows ? dpv[t] : 0.f;
+            const float wv = t < n_rows ? pdv[t] : 0.f;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                gk[e] += wk * (float)qa[i][e];
+                gv[e] += wv * (float)da[i][e];
+            }
+        }
+        t0 += RC;
+        if (t0 >= n_rows) break;
+        load_rows(qa, qp, q_ssb, t0, n_rows);
+        load_rows(da, dcp, dctx_ssb, t0, n_rows);
     }
     if constexpr (LS == 3 && E == 8) {
         const float ok = group8_transpose_sum(gk, lane), ov = group8_transpose_sum(gv, lane);
@@ -927,8 +1242,7 @@ static void launch_attn_fwd(const Ctx& c, const void* q, int64_t q_bs, const voi
         Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.eval_rows, c.seed_base)
 #define MSSR_FWD_TILED(LS)                            \
     do {                                              \
-        if (Lk <= 4 * (64 >> LS)) MSSR_FWD_TILED_N(LS, 4); \
-        else MSSR_FWD_TILED_N(LS, 8);                 \
+        MSSR_FWD_TILED_N(LS, 4);                      \
     } while (0)
     switch (sh) {
         case 1: MSSR_FWD_TILED(1); return;
@@ -955,8 +1269,17 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     const int bh = c.Bc * p->heads;
     const int sh = tiled_shift<T>(dh, {q, k, v, dctx, dq, dk_out, dv_out},
                                   {q_bs, kv_bs, kv_ts, dctx_bs, dq_bs, q_ss, dctx_ss, out_bs});
+    // the streaming kernel's lanes carry 32-bit byte offsets from per-(sentence, head) bases
+    const int64_t es = (int64_t)sizeof(T), lim = (int64_t)1 << 32;
+    const bool offsets32 = (int64_t)Lk * kv_ts * es < lim && (!gather || ((int64_t)p->T * q_ss * es < lim &&
+                                                                          (int64_t)p->T * dctx_ss * es < lim));
 #define MSSR_BWD_TILED_N(LS, NL)                                                                                    \
     attn_step_bwd_tiled_kernel<T, LS, NL><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                    \
+        (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,    \
+        dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,  \
+        c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads, c.seed_base)
+#define MSSR_BWD_STREAM(LS)                                                                                         \
+    attn_step_bwd_stream_kernel<T, LS, 4><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(                                     \
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,    \
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,  \
         c.Bc, p->heads, dh, Lk, 1.0f / sqrtf((float)dh), p_drop, seed, c.hash_row_off * p->heads, c.seed_base)
@@ -964,6 +1287,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     do {                                                                                \
         const int need = gather && p->T - step > Lk ? p->T - step : Lk;                 \
         if (need <= 4 * (64 >> LS)) MSSR_BWD_TILED_N(LS, 4);                            \
+        else if (offsets32) MSSR_BWD_STREAM(LS);                                        \
         else MSSR_BWD_TILED_N(LS, 8);                                                   \
     } while (0)
     switch (sh) {
@@ -975,6 +1299,7 @@ static void launch_attn_bwd(const Ctx& c, const void* q, int64_t q_bs, const voi
     }
 #undef MSSR_BWD_TILED
 #undef MSSR_BWD_TILED_N
+#undef MSSR_BWD_STREAM
     attn_step_bwd_kernel<T><<<dim3((bh + 3) / 4), 256, 0, c.s>>>(
         (const T*)q, q_bs, (const T*)k, (const T*)v, kv_bs, kv_ts, mask, mask_bs, (const T*)dctx, dctx_bs, (T*)dq,
         dq_bs, ds_out, pd_out, slab_bhs, gather, step, p->T, slab_ss, q_ss, dctx_ss, (T*)dk_out, (T*)dv_out, out_bs,
@@ -1065,8 +1390,8 @@ struct Geo {
     char* dqkv(int l, int step) const { return rows(p->dqkv, (int64_t)l * T + step, 3 * d); }
     char* dctx(int l, int which, int step) const { return rows(p->dctx, ((int64_t)l * 2 + which) * T + step, d); }
     // per-step score-gradient slabs [n_layers][2 = ds|pd][T][B*H][W], W = T (self) or Ls (context)
-    float* ds_self(int l, int which, int step) const {
-        return p->ds_self + ((((int64_t)l * 2 + which) * T + step) * B + r0) * p->heads * T;
+    float* ds_self(int l) const {               // pairs [key][step][B * heads] of layer l, first (sentence, head) of this chunk
+        return p->ds_self + (((int64_t)l * T * T * B + r0) * p->heads) * 2;
     }
     float* ds_ctx(int l, int which, int step) const {
         return p->ds_ctx + ((((int64_t)l * 2 + which) * T + step) * B + r0) * p->heads * Ls;
@@ -1340,8 +1665,8 @@ static int step_bwd(const Ctx& c, int step) {
                           0, 1.f)))
             return rc;
         DT_CALL(c, launch_attn_bwd, c, qkv_s, G.qkv_bs(), qkv_0 + (int64_t)d * es, qkv_0 + 2LL * d * es, G.qkv_bs(),
-                (int64_t)3 * d, G.self_mask(), p->T, dctx1, d, dqkv_s, 3 * d, G.ds_self(l, 0, step), G.ds_self(l, 1, step),
-                p->T, 1, step, (int64_t)B * p->heads * p->T, (int64_t)3 * d, (int64_t)B * d,
+                (int64_t)3 * d, G.self_mask(), p->T, dctx1, d, dqkv_s, 3 * d, G.ds_self(l), nullptr,
+                (int64_t)B * p->heads, 1, step, 0, (int64_t)3 * d, (int64_t)B * d,
                 dqkv_s + (int64_t)d * es, dqkv_s + 2LL * d * es, 3 * d, step + 1, pa, site_seed(c, step, l, 1));
         if ((rc = gemm_nt(c, dqkv_s, 3 * d, L.wt_qkv, 3 * d, dn1, d, R, d, 3 * d, nullptr, 0, nullptr, 0, nullptr, 0, 1.f,
                           0.f, c.dt, 0.f, 0)))

@@ -580,7 +580,7 @@ class _SoftDecode(Function):
         g = dict(dprobs=dprobs,
                  dlogits=pe("dlogits", R, Vp, zero=_regime(spec)), dX=pe("dX", 2, B, d), dqkv=pe("dqkv", NL, R, 3 * d),
                  dactD=pe("dactD", NL, 7, R, d), dactF=pe("dactF", NL, R, ff), dctx=pe("dctx", NL, 2, R, d),
-                 ds_self=pe("ds_self", NL, 2, T, B * H, T, dtype=torch.float32),
+                 ds_self=pe("ds_self", NL, T, T, B * H, 2, dtype=torch.float32),      # [key][step][sentence, head] pairs
                  ds_ctx=pe("ds_ctx", NL, 2, T, B * H, Ls, dtype=torch.float32),
                  d_e=pe("d_e", R, d), dnf=pe("dnf", R, d))
         for name, t in g.items():
@@ -592,7 +592,11 @@ class _SoftDecode(Function):
 
         def skipped(name):          # what this regime's sweep leaves unwritten in a [.., T, B, n] gradient slab
             def fill(t):
-                v = t.view(NL * 2, T, B, -1) if name in ("ds_self", "ds_ctx") else t.view(-1, T, B, t.shape[-1])
+                if name == "ds_self":       # [layer][key][step][sentence][head, 2]
+                    if late_row0:
+                        t.view(NL, T, T, B, H * 2)[:, :, late_step:, E0:late_row0].zero_()
+                    return
+                v = t.view(NL * 2, T, B, -1) if name == "ds_ctx" else t.view(-1, T, B, t.shape[-1])
                 if late_row0:
                     v[:, late_step:, E0:late_row0].zero_()
                 if E0 and name in ("dqkv", "dactD", "dactF", "d_e", "dnf"):

@@ -209,6 +209,63 @@ def test_engine_long_sequences_fp32(ops):
     assert_grads({k: ge[k] for k in dec_keys}, {k: gm[k] for k in dec_keys}, 5e-4, "decoder")
 
 
+def test_engine_long_sequences_bf16_wide_heads(ops):
+    """bf16, 64-wide heads (8 lanes per row: the README head shape), 70 source words and 45 steps with ragged lengths:
+    the backward's streaming attention kernel (one pass over K | V, split-softmax merge, packed-bf16 dots) and the
+    multi-chunk forward, against the modular bf16 path; gradients by direction and magnitude."""
+    cfg = MSSRConfig.small(d_model=128, heads=2, d_ff=256)
+    ops.set_compute_dtype(torch.bfloat16)
+    B, Ls, steps = 5, 70, 45
+    model, src, lens, mem = setup(cfg, B, Ls, seed=8)
+    model.train()
+    w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
+    mem = mem.to(torch.bfloat16)
+    pe, ge_mem, ge, _, _ = run("decode_batch_ori", model, cfg, src, lens, mem, steps, w)
+    pm, gm_mem, gm, _, _ = run("decode_batch_modular", model, cfg, src, lens, mem, steps, w)
+    assert_close(pe, pm, 2e-2, "probs bf16")
+
+    def cos(a, b):
+        a, b = a.double().flatten(), b.double().flatten()
+        return float((a * b).sum() / (a.norm() * b.norm() + 1e-30))
+
+    assert cos(ge_mem, gm_mem) > 0.99, cos(ge_mem, gm_mem)
+    for k in gm:
+        if not (k.startswith("decoder.") or k.startswith("generator.")) or "attn" not in k:
+            continue
+        if k.endswith("linear_keys.bias"):      # a key bias shifts every score of a query alike: its gradient is rounding noise
+            continue
+        assert torch.isfinite(ge[k]).all(), k
+        assert cos(ge[k], gm[k]) > 0.98, (k, cos(ge[k], gm[k]))
+        assert 0.9 < float(ge[k].norm() / gm[k].norm()) < 1.1, k
+
+
+def test_engine_long_sequences_dropout_fp32(ops):
+    """The streaming backward must regenerate the forward's attention-dropout decisions for keys beyond the first
+    chunk too: <grad, v> against the directional finite difference of the seed-fixed function at 70 keys / 67 steps."""
+    from mssrnet_style_transfer_amd import train_and_translate as TT
+    cfg = MSSRConfig.small(dropout=0.0, attention_dropout=0.3)
+    B, Ls, steps = 3, 70, 67
+    model, src, lens, mem = setup(cfg, B, Ls, seed=9)
+    model.train()
+    w = torch.randn(steps, B, cfg.vocab_size, device="cuda")
+
+    def f(m):
+        ops._state["seed_counter"] = 4321
+        probs, _, _ = TT.decode_batch_ori(model, cfg, src, None, m, lens, steps)
+        return probs
+
+    m = mem.clone().requires_grad_(True)
+    p = f(m)
+    (p * w).sum().backward()
+    v = m.grad / m.grad.norm() * float(mem.numel()) ** 0.5
+    analytic = float((m.grad * v).sum())
+    with torch.no_grad():
+        assert torch.equal(f(mem), p.detach()), "same seed must give the same masks"
+        eps = 2e-3
+        fd = float((((f(mem + eps * v) - f(mem - eps * v)) * w).sum() / (2 * eps)).double())
+    assert abs(analytic - fd) <= 2e-2 * max(abs(fd), 1e-3), (analytic, fd)
+
+
 @pytest.mark.parametrize("B,Ls,steps", [(1, 1, 1), (2, 1, 3), (1, 3, 2), (17, 2, 1)])
 def test_engine_smallest_shapes_fp32(ops, B, Ls, steps):
     """One sentence, one source word, one step: the corners of the engine's range against the modular path."""
