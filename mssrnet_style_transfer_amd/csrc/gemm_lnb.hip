@@ -35,7 +35,7 @@ template <typename TO, int LNB_FN>
 __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p, const int region_bytes) {
     constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
     extern __shared__ __attribute__((aligned(1024))) unsigned char lnb_smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: region / k-range arithmetic on the SALU
     const int64_t n0 = (int64_t)blockIdx.x * LNB_TSN, m0 = (int64_t)blockIdx.y * 16;
     const int steps = (int)(p.k / 32);
     const bf16* DY = reinterpret_cast<const bf16*>(p.a);

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
     constexpr int TE = TSM * TSN;
     constexpr int EPT = TE / SK_THREADS;
     extern __shared__ __attribute__((aligned(1024))) unsigned char sk_smem[];     // the kernel's ONLY LDS object
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: region / k-range arithmetic on the SALU
     dbg_stamp(p, 0);
     const int64_t n0 = (int64_t)blockIdx.x * TSN, m0 = (int64_t)blockIdx.y * TSM;
     const int split = blockIdx.z;
@@ -247,41 +247,52 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
     const int drow = lane >> 3, dpc = lane & 7;
     const int k_last = (int)p.k - 8;
     {
-        const bf16* asrc[TSM / 8];
-        const bf16* wsrc[TSN / 8];
-        int achunk[TSM / 8], wchunk[TSN / 8];
-        // rows / columns as 32-bit integers (m, n < 2^31: the grid could not cover more), one 64-bit product per pointer
+        // 32-bit byte offsets from the (scalar) operand bases: the host checked that both operands span < 4 GB
+        uint32_t aoff[TSM / 8], woff[TSN / 8];
+        const char* Ab = reinterpret_cast<const char*>(A);
+        const char* Wb = reinterpret_cast<const char*>(W);
         const int mi = (int)p.m, ni = (int)p.n, m0i = (int)m0, n0i = (int)n0;
+        const uint32_t a_rsb = (uint32_t)p.a_rs * 2u, b_csb = (uint32_t)p.b_cs * 2u;
 #pragma unroll
         for (int g = 0; g < TSM / 8; ++g) {
             const int r = g * 8 + drow;
             const int gr = min(m0i + r, mi - 1);
-            asrc[g] = A + (int64_t)gr * p.a_rs;
-            achunk[g] = (dpc ^ sk_swz(r)) * 8;
+            aoff[g] = (uint32_t)gr * a_rsb + (uint32_t)((dpc ^ sk_swz(r)) * 16);
         }
 #pragma unroll
         for (int g = 0; g < TSN / 8; ++g) {
             const int r = g * 8 + drow;
             const int gn = min(n0i + r, ni - 1);
-            wsrc[g] = W + (int64_t)gn * p.b_cs;
-            wchunk[g] = (dpc ^ sk_swz(r)) * 8;
+            woff[g] = (uint32_t)gn * b_csb + (uint32_t)((dpc ^ sk_swz(r)) * 16);
         }
+        // a chunk past the end of K (second half of an odd count of k-steps) is never multiplied: clamp the lanes whose
+        // 16 bytes would start beyond k - 8 (only the last block of the range can hold such chunks)
+        const uint32_t kb_last = (uint32_t)k_last * 2u;
 #pragma unroll
         for (int bl = 0; bl < KBW; ++bl) {
             if (b_lo + bl >= nb) break;                          // wave-uniform: the last wave's range may be short
-            const int k0 = (s_begin + 2 * (b_lo + bl)) * 32;
+            const uint32_t kb0 = (uint32_t)((s_begin + 2 * (b_lo + bl)) * 32) * 2u;      // scalar
+            const bool tail = kb0 + 112u > kb_last;              // scalar: some chunk of this block may pass k - 8
 #pragma unroll
             for (int g = 0; g < TSN / 8; ++g) {
-                int k = k0 + wchunk[g];
-                k = k <= k_last ? k : k_last;    // second half past the end (odd count of k-steps): never multiplied
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[g] + k),
+                uint32_t o = woff[g] + kb0;
+                if (tail) {
+                    const uint32_t rowb = woff[g] - (uint32_t)((dpc ^ sk_swz(g * 8 + drow)) * 16);
+                    const uint32_t kb = kb0 + (uint32_t)((dpc ^ sk_swz(g * 8 + drow)) * 16);
+                    o = rowb + (kb <= kb_last ? kb : kb_last);
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wb + o),
                                                  (__attribute__((address_space(3))) void*)(regW + (bl * TSN + g * 8) * 128), 16, 0, 0);
             }
 #pragma unroll
             for (int g = 0; g < TSM / 8; ++g) {
-                int k = k0 + achunk[g];
-                k = k <= k_last ? k : k_last;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(asrc[g] + k),
+                uint32_t o = aoff[g] + kb0;
+                if (tail) {
+                    const uint32_t rowb = aoff[g] - (uint32_t)((dpc ^ sk_swz(g * 8 + drow)) * 16);
+                    const uint32_t kb = kb0 + (uint32_t)((dpc ^ sk_swz(g * 8 + drow)) * 16);
+                    o = rowb + (kb <= kb_last ? kb : kb_last);
+                }
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Ab + o),
                                                  (__attribute__((address_space(3))) void*)(regA + (bl * TSM + g * 8) * 128), 16, 0, 0);
             }
         }
@@ -533,6 +544,8 @@ static bool skinny_dma_launch(const GemmArgs& a, const dim3 grid, hipStream_t s,
     static const bool enabled = [] { const char* e = getenv("MSSR_SKINNY_DMA"); return !e || atoi(e) != 0; }();
     static const bool splitk_too = [] { const char* e = getenv("MSSR_SKINNY_DMA_SPLITK"); return e && atoi(e) != 0; }();
     if (!enabled || (a.ksplit > 1 && !splitk_too)) return false;      // split-K slabs (K = 9632): 25.8 -> 35.3 us with DMA
+    // the kernel's lanes carry 32-bit byte offsets from the operand bases
+    if (a.m * a.a_rs * 2 >= ((int64_t)1 << 32) || a.n * a.b_cs * 2 >= ((int64_t)1 << 32)) return false;
     const int64_t steps = (a.k / 32 + a.ksplit - 1) / a.ksplit;
     const int nb = (int)((steps + 1) / 2), kbw = (nb + 3) / 4;
     // vector epilogue (the 4 / 2 consecutive columns of a thread as one access): 32 x 32 and 16 x 32 tiles

@@ -54,6 +54,8 @@ RULES = [
     # not GEMMs, but the kernels config 5 spends 40 % of its time in (their HBM rate = this traffic / rocprofv3 duration)
     (re.compile(r"attn_step_(fwd|bwd)_tiled_kernelIDF16bLi\d+ELi(\d+)E"),
      lambda m: "attn_step_%s_tiled_kernel<bf16,%s>" % (m.group(1), m.group(2))),
+    (re.compile(r"attn_step_bwd_stream_kernelIDF16bLi\d+ELi(\d+)E"),
+     lambda m: "attn_step_bwd_stream_kernel<bf16,%s>" % m.group(1)),
     (re.compile(r"gemm_kernelIDF16bDF16bLi(\d+)ELi\d+E"), lambda m: "gemm_kernel<bf16,bf16,%s>" % m.group(1)),
     (re.compile(r"gemm_kernelIDF16bfLi(\d+)ELi\d+E"), lambda m: "gemm_kernel<bf16,f32,%s>" % m.group(1)),
     (re.compile(r"gemm_kernel<float, float, (\d+), \d+>"), lambda m: "gemm_kernel<f32,f32,%s>" % m.group(1)),
