@@ -36,8 +36,11 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
     constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
     extern __shared__ __attribute__((aligned(1024))) unsigned char lnb_smem[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: region / k-range arithmetic on the SALU
-    const int64_t n0 = (int64_t)blockIdx.x * LNB_TSN, m0 = (int64_t)blockIdx.y * 16;
-    const int steps = (int)(p.k / 32);
+    // 32-bit index arithmetic throughout (the host checked that every operand spans < 4 GB and m, n, k < 2^31): lanes
+    // carry byte offsets from the scalar operand bases
+    const int n0 = (int)blockIdx.x * LNB_TSN, m0 = (int)blockIdx.y * 16;
+    const int mi = (int)p.m, ni = (int)p.n, ki = (int)p.k;
+    const int steps = ki >> 5;
     const bf16* DY = reinterpret_cast<const bf16*>(p.a);
     const bf16* W = reinterpret_cast<const bf16*>(p.b);
     const bf16* X = reinterpret_cast<const bf16*>(p.lnb_x);
@@ -50,31 +53,35 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
     unsigned char* rW = region + 6144;           // [LNB_TSN][128 B]
     float* rstat = reinterpret_cast<float*>(region + 6144 + LNB_TSN * 128);     // [16][2]
     const bool wave_live = 2 * wave < steps;     // K < 512: the upper waves own nothing
-    const int64_t k0 = wave_live ? (int64_t)wave * 64 : 0;
-    const int64_t k_last = p.k - 8;
+    const int k0 = wave_live ? wave * 64 : 0;
+    const int k_last = ki - 8;
+    const uint32_t a_rsb = (uint32_t)p.a_rs * 2u, b_csb = (uint32_t)p.b_cs * 2u;
     {
         const int drow = lane >> 3, dpc = lane & 7;
+        const char* DYb = reinterpret_cast<const char*>(DY);
+        const char* Xb = reinterpret_cast<const char*>(X);
+        const char* DRb = reinterpret_cast<const char*>(DR);
+        const char* Wb = reinterpret_cast<const char*>(W);
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
             const int r = g * 8 + drow;
-            const int64_t gr = m0 + r;
-            int64_t k = k0 + (dpc ^ lnb_swz(r)) * 8;
+            int k = k0 + (dpc ^ lnb_swz(r)) * 8;
             k = k <= k_last ? k : k_last;            // second half past the end (odd count of k-steps): never used
-            const int64_t off = (gr < p.m ? gr : p.m - 1) * p.a_rs + k;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DY + off),
+            const uint32_t off = (uint32_t)min(m0 + r, mi - 1) * a_rsb + (uint32_t)k * 2u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DYb + off),
                                              (__attribute__((address_space(3))) void*)(rDY + g * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(X + off),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Xb + off),
                                              (__attribute__((address_space(3))) void*)(rX + g * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DR + off),
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(DRb + off),
                                              (__attribute__((address_space(3))) void*)(rDR + g * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < LNB_TSN / 8; ++g) {
             const int r = g * 8 + drow;
-            const int64_t gn = n0 + r;
-            int64_t k = k0 + (dpc ^ lnb_swz(r)) * 8;
+            int k = k0 + (dpc ^ lnb_swz(r)) * 8;
             k = k <= k_last ? k : k_last;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(W + (gn < p.n ? gn : p.n - 1) * p.b_cs + k),
+            const uint32_t off = (uint32_t)min(n0 + r, ni - 1) * b_csb + (uint32_t)k * 2u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Wb + off),
                                              (__attribute__((address_space(3))) void*)(rW + g * 1024), 16, 0, 0);
         }
     }
@@ -83,22 +90,22 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
     // converted the gate values here (an `s_waitcnt vmcnt(0)` of the compiler's), so the statistics / gamma loads were
     // not even issued, and no dropout decision hashed, before the operand tiles had landed.
     const int fr = lane & 15, fc = lane >> 4;
-    const int64_t arl = m0 + fr;
-    const bool row_ok = arl < p.m;
-    const int64_t ar = row_ok ? arl : p.m - 1;
-    const int64_t arow = ar * p.a_rs;
+    const int arl = m0 + fr;
+    const bool row_ok = arl < mi;
+    const int ar = row_ok ? arl : mi - 1;
+    const int64_t arow = (int64_t)ar * p.a_rs;
     constexpr int EPT = (16 * LNB_TSN + LNB_THREADS - 1) / LNB_THREADS;
     bf16 graw[EPT];
     bool eok[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         const int e = threadIdx.x + i * LNB_THREADS;
-        const int64_t erow = m0 + e / LNB_TSN, ecol = n0 + e % LNB_TSN;
-        eok[i] = e < 16 * LNB_TSN && erow < p.m && ecol < p.n;
+        const int erow = m0 + e / LNB_TSN, ecol = n0 + e % LNB_TSN;
+        eok[i] = e < 16 * LNB_TSN && erow < mi && ecol < ni;
         // an UNCONDITIONAL load from a clamped address (no gate: an element of dy, never used): a select between a
         // constant and the loaded value would make the compiler wait for the load right here
-        const int64_t gr = erow < p.m ? erow : p.m - 1, gc = ecol < p.n ? ecol : p.n - 1;
-        const bf16* gp = p.gate ? reinterpret_cast<const bf16*>(p.gate) + gr * p.ldg + gc : DY + gr * p.a_rs;
+        const int gr = erow < mi ? erow : mi - 1, gc = ecol < ni ? ecol : ni - 1;
+        const bf16* gp = p.gate ? reinterpret_cast<const bf16*>(p.gate) + (int64_t)gr * p.ldg + gc : DY + (int64_t)gr * p.a_rs;
         graw[i] = *gp;
     }
     const float mu = p.lnb_mean[ar], rs = p.lnb_rstd[ar];
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
     f32x4 g0[2], g1[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        int64_t k = k0 + 32 * h + 8 * fc;
+        int k = k0 + 32 * h + 8 * fc;
         k = k <= k_last ? k : k_last;
         g0[h] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k);
         g1[h] = *reinterpret_cast<const f32x4*>(p.lnb_gamma + k + 4);
@@ -167,8 +174,9 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
         c1 += stat0[w * rstride + fr * 2];
         c2 += stat0[w * rstride + fr * 2 + 1];
     }
-    c1 /= (float)p.k;
-    c2 /= (float)p.k;
+    const float inv_k = 1.0f / (float)ki;
+    c1 *= inv_k;
+    c2 *= inv_k;
     const float sc = p.lnb_extra / (1.0f - p.lnb_p);
     const bool writer = blockIdx.x == 0 && row_ok;
     f32x4 acc[LNB_FN];
@@ -176,7 +184,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
     for (int j = 0; j < LNB_FN; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-        const int64_t k = k0 + 32 * h + 8 * fc;
+        const int k = k0 + 32 * h + 8 * fc;
         bf16x8 dxv, dx2v;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -220,7 +228,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
         for (int w = 0; w < LNB_NW; ++w) v += red0[w * rstride + e];
         v *= p.alpha;
         if (p.gate) v = to_f(graw[i]) > 0.f ? v : 0.f;
-        C[(m0 + rr) * p.ldc + n0 + cc] = from_f<TO>(v);
+        C[(int64_t)(m0 + rr) * p.ldc + n0 + cc] = from_f<TO>(v);
     }
 }
 
@@ -244,6 +252,8 @@ bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s) {
     if (a.m < 1 || a.n < 1 || a.k < 32 || a.k % 32 != 0 || a.k > LNB_NW * 64) return false;
     if (a.a_cs != 1 || a.b_rs != 1 || a.a_rs % 8 != 0 || a.b_cs % 8 != 0) return false;
     if ((a.m + 15) / 16 > 65535) return false;
+    // the kernel's lanes carry 32-bit byte offsets from the operand bases (dy, x and dres share dy's row stride)
+    if (a.m * a.a_rs * 2 >= ((int64_t)1 << 32) || a.n * a.b_cs * 2 >= ((int64_t)1 << 32)) return false;
     if (a.lnb_dres == a.lnb_dx) return false;
     for (const void* q : {a.a, a.b, a.lnb_x, a.lnb_dres, (const void*)a.lnb_dx, (const void*)a.lnb_dx2,
                           (const void*)a.lnb_gamma})
