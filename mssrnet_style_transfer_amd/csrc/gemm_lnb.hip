@@ -31,7 +31,7 @@ __device__ __forceinline__ int lnb_swz(int r) { return (r >> 1) & 7; }
 // Every wave copies its 64-wide k-block of dy, x, dres (16 rows x 128 bytes each) and of its W columns into its own
 // LDS region with whole 128-byte lines (10 / 14 DMA instructions), reads the fragments back by ds_read_b128 from a
 // 16-byte-chunk XOR-swizzled image, and later reuses the region for its partial tile.  One LDS object only.
-template <typename TO, int LNB_FN>
+template <typename TO, int LNB_FN, bool DROP>
 __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p, const int region_bytes) {
     constexpr int LNB_TSN = 16 * LNB_FN;       // tile columns
     extern __shared__ __attribute__((aligned(1024))) unsigned char lnb_smem[];
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
     for (int h = 0; h < 2; ++h) {
         const uint64_t i2 = (uint64_t)((ar + p.lnb_row_off) * p.k + k0 + 32 * h + 8 * fc) >> 1;   // a multiple of 4 pairs
 #pragma unroll
-        for (int q = 0; q < 4; ++q) kp[h][q] = p.lnb_p > 0.f ? keep16_pair(lnb_seed, i2 + q, thr) : 3u;
+        for (int q = 0; q < 4; ++q) kp[h][q] = DROP ? keep16_pair(lnb_seed, i2 + q, thr) : 3u;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bf16x8 fb[2][LNB_FN], fdy[2], fx[2], fr_[2];
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
             const float o = (has_res ? (float)fr_[h][j] : 0.f) + rs * (a - c1 - xh * c2);
             const bf16 ob = (bf16)o;
             const float ov = (float)ob;               // dx IS stored in bf16: replay from the stored value
-            const float o2 = p.lnb_p > 0.f ? (((kp[h][j >> 1] >> (j & 1)) & 1u) ? ov * sc : 0.f) : ov * p.lnb_extra;
+            const float o2 = DROP ? (((kp[h][j >> 1] >> (j & 1)) & 1u) ? ov * sc : 0.f) : ov * p.lnb_extra;
             dxv[j] = ob;
             dx2v[j] = (bf16)o2;
         }
@@ -239,10 +239,15 @@ template <typename TO, int LNB_FN>
 static bool lnb_launch(const GemmArgs& a, const dim3 grid, hipStream_t s) {
     const int region = lnb_region_bytes<LNB_FN>();
     const int lds = LNB_NW * region;
-    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lnb_kernel<TO, LNB_FN>),
-                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
+    static const bool attr_ok =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lnb_kernel<TO, LNB_FN, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_lnb_kernel<TO, LNB_FN, false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess;
     if (lds > 64 * 1024 && !attr_ok) return false;
-    klaunch(gemm_lnb_kernel<TO, LNB_FN>, grid, dim3(LNB_THREADS), (unsigned)lds, s, a, region);
+    // the dropout replay as a template parameter: no per-element branch on p in the row arithmetic
+    if (a.lnb_p > 0.f) klaunch(gemm_lnb_kernel<TO, LNB_FN, true>, grid, dim3(LNB_THREADS), (unsigned)lds, s, a, region);
+    else klaunch(gemm_lnb_kernel<TO, LNB_FN, false>, grid, dim3(LNB_THREADS), (unsigned)lds, s, a, region);
     return true;
 }
 
