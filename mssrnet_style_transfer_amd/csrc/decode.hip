@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
 #pragma unroll
         for (int i = 0; i < AT_NL; ++i) {
             if (t0 + i * RPL >= Lk) break;                  // uniform: the rest of the chunk is past the last key
-            const float a = group_sum<LS>(dot16<T>(kt[i], qf));
+            const float a = group_sum<LS>(dot16_packed<T>(kt[i], qf));
             const int t = t0 + i * RPL + r;
             if (c == 0 && t < Lk) s[t] = a * scale;
         }
@@ -577,8 +577,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
 #pragma unroll
         for (int i = 0; i < AT_NL; ++i) {
             if (t0 + i * RPL >= Lk) break;
-            const float a = group_sum<LS>(dot16<T>(kt[i], qf));
-            const float g = group_sum<LS>(dot16<T>(vt[i], df));
+            const float a = group_sum<LS>(dot16_packed<T>(kt[i], qf));
+            const float g = group_sum<LS>(dot16_packed<T>(vt[i], df));
             const int t = t0 + i * RPL + r;
             if (c == 0 && t < Lk) {
                 s[t] = a * scale;
