@@ -325,6 +325,20 @@ __device__ __forceinline__ float dot16_packed(const typename Row16<T>::V& a, con
     }
 }
 
+// acc += w * row, two elements per instruction (v_pk_fma_f32 on adjacent accumulator registers)
+template <typename T>
+__device__ __forceinline__ void axpy16(float (&acc)[Row16<T>::E], float w, const typename Row16<T>::V& x) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int q = 0; q < Row16<T>::E / 2; ++q) {
+        f2 a = {acc[2 * q], acc[2 * q + 1]};
+        const f2 v = {(float)x[2 * q], (float)x[2 * q + 1]};
+        a += w * v;
+        acc[2 * q] = a[0];
+        acc[2 * q + 1] = a[1];
+    }
+}
+
 // sum over the 2^LS adjacent lanes that hold one row (every lane of the group gets the total): DPP moves, no LDS
 // crossbar trip (quad_perm xor 1, xor 2, row_half_mirror, row_mirror)
 template <int LS>
@@ -490,8 +504,7 @@ __global__ __launch_bounds__(256) void attn_step_fwd_tiled_kernel(
             if (t0 + i * RPL >= Lk) break;
             const int t = t0 + i * RPL + r;
             const float pt = t < Lk ? s[t] : 0.f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] += pt * (float)vt[i][e];
+            axpy16<T>(acc, pt, vt[i]);
         }
     };
     ctxacc(v0, 0);
@@ -664,8 +677,7 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
             if (t0 + i * RPL >= Lk) break;
             const int t = t0 + i * RPL + r;
             const float w = t < Lk ? s[t] : 0.f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) acc[e] += w * (float)kt[i][e];
+            axpy16<T>(acc, w, kt[i]);
         }
     };
     dqacc(k0, 0);
@@ -693,11 +705,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_tiled_kernel(
             const int t = t0 + i * RPL + r;
             const float wk = t < n_rows ? dpv[t] : 0.f;
             const float wv = t < n_rows ? pdv[t] : 0.f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                gk[e] += wk * (float)qt[i][e];
-                gv[e] += wv * (float)dt[i][e];
-            }
+            axpy16<T>(gk, wk, qt[i]);
+            axpy16<T>(gv, wv, dt[i]);
         }
     };
     gacc(q0, d0, 0);
@@ -883,12 +892,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_stream_kernel(
             rn += ex * g[i];
             const float ek = mc[i] ? 0.f : ex;          // masked_fill: no gradient to a masked score
             const float wk = ek * g[i];
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const float kf = (float)kc[i][e];
-                A[e] += wk * kf;
-                Bv[e] += ek * kf;
-            }
+            axpy16<T>(A, wk, kc[i]);
+            axpy16<T>(Bv, ek, kc[i]);
         }
         t0 += RC;
         if (t0 >= Lk) break;
@@ -967,11 +972,8 @@ __global__ __launch_bounds__(256) void attn_step_bwd_stream_kernel(
             const int t = t0 + i * RPL + r;
             const float wk = t < n_rows ? dpv[t] : 0.f;
             const float wv = t < n_rows ? pdv[t] : 0.f;
-#pragma unroll
-            for (int e = 0; e < E; ++e) {
-                gk[e] += wk * (float)qa[i][e];
-                gv[e] += wv * (float)da[i][e];
-            }
+            axpy16<T>(gk, wk, qa[i]);
+            axpy16<T>(gv, wv, da[i]);
         }
         t0 += RC;
         if (t0 >= n_rows) break;
