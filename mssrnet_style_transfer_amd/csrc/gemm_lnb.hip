@@ -128,6 +128,12 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
 #pragma unroll
         for (int q = 0; q < 4; ++q) kp[h][q] = DROP ? keep16_pair(lnb_seed, i2 + q, thr) : 3u;
     }
+    // pin the decisions ahead of the wait: nothing orders plain arithmetic against the wait, and the scheduler had
+    // sunk most of the hashes behind the barrier, onto the critical path between the statistics and the MFMAs
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(kp[h][q]));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bf16x8 fb[2][LNB_FN], fdy[2], fx[2], fr_[2];
     bool live[2];
