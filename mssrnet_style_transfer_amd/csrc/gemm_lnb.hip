@@ -129,11 +129,15 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
         for (int q = 0; q < 4; ++q) kp[h][q] = DROP ? keep16_pair(lnb_seed, i2 + q, thr) : 3u;
     }
     // pin the decisions ahead of the wait: nothing orders plain arithmetic against the wait, and the scheduler had
-    // sunk most of the hashes behind the barrier, onto the critical path between the statistics and the MFMAs
+    // sunk most of the hashes behind the barrier, onto the critical path between the statistics and the MFMAs -- and
+    // with them the two divisions below (a ~12-instruction dependent chain each)
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int q = 0; q < 4; ++q) asm volatile("" ::"v"(kp[h][q]));
+    float inv_k = 1.0f / (float)ki;
+    float sc = p.lnb_extra / (1.0f - p.lnb_p);
+    asm volatile("" : "+v"(inv_k), "+v"(sc));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     bf16x8 fb[2][LNB_FN], fdy[2], fx[2], fr_[2];
     bool live[2];
@@ -180,10 +184,8 @@ __global__ __launch_bounds__(LNB_THREADS) void gemm_lnb_kernel(const GemmArgs p,
         c1 += stat0[w * rstride + fr * 2];
         c2 += stat0[w * rstride + fr * 2 + 1];
     }
-    const float inv_k = 1.0f / (float)ki;
     c1 *= inv_k;
     c2 *= inv_k;
-    const float sc = p.lnb_extra / (1.0f - p.lnb_p);
     const bool writer = blockIdx.x == 0 && row_ok;
     f32x4 acc[LNB_FN];
 #pragma unroll
