@@ -277,7 +277,9 @@ bool gemm_lnb_try(const GemmArgs& a, int out_dtype, hipStream_t s) {
         return e ? (int64_t)atoll(e) : (int64_t)1024;      // WGAN step 54.56 ms with 16x32 everywhere, 54.07 with 16x64
                                                             // from n = 1024 (the FFN inner gradient), 54.69 from n = 512
     }();
-    if (a.n >= wide_n) {
+    // ... and from the row count at which the wide tiles still fill the chip (256 blocks: 512 rows at n = 512): half as
+    // many repeats of the row work, half the operand traffic (--workload long, 512-768 rows: 518 -> 507 ms per step)
+    if (a.n >= wide_n || ((a.m + 15) / 16) * ((a.n + 63) / 64) >= 256) {
         const dim3 grid((unsigned)((a.n + 63) / 64), (unsigned)((a.m + 15) / 16), 1);
         return out_dtype == MSSR_BF16 ? lnb_launch<bf16, 4>(a, grid, s) : lnb_launch<float, 4>(a, grid, s);
     }
