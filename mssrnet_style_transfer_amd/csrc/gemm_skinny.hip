@@ -365,6 +365,10 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
     float sx[FM], sxx[FM];
 #pragma unroll
     for (int f = 0; f < FM; ++f) sx[f] = sxx[f] = 0.f;
+    // uniform reciprocals of the epilogue, taken here (pinned: nothing else orders arithmetic against the wait) instead of as
+    // three ~12-instruction division chains behind the last barrier
+    float inv_k = 1.0f / (float)p.k, keep_scale = 1.0f / (1.0f - p.drop_p);
+    asm volatile("" : "+v"(inv_k), "+v"(keep_scale));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's region is complete (and only it reads it)
     dbg_stamp(p, 2);
     const int fr = lane & 15, fc = lane >> 4;
@@ -479,15 +483,14 @@ __global__ __launch_bounds__(SK_THREADS) void gemm_skinny_dma_kernel(const GemmA
         const float* st = red0 + TE + rl * 2;
         const float s1 = (st[0] + st[rstride]) + (st[2 * rstride] + st[3 * rstride]);
         const float s2 = (st[1] + st[rstride + 1]) + (st[2 * rstride + 1] + st[3 * rstride + 1]);
-        mean = s1 / (float)p.k;
-        const float var = fmaxf(s2 / (float)p.k - mean * mean, 0.f);
+        mean = s1 * inv_k;
+        const float var = fmaxf(s2 * inv_k - mean * mean, 0.f);
         rstd = rsqrtf(var + p.ln_eps);
         if (blockIdx.x == 0 && (e0 % TSN) == 0) {
             if (p.ln_mean) p.ln_mean[erow] = mean;
             if (p.ln_rstd) p.ln_rstd[erow] = rstd;
         }
     }
-    const float keep_scale = 1.0f / (1.0f - p.drop_p);
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
         float x = v[i];
