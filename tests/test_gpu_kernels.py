@@ -636,6 +636,27 @@ def test_gemm_skinny_path(ops, M, N, K):
     assert_close(kept[sel], (out32 / 0.75)[sel], 1e-5, "dropout scaling")
 
 
+def test_gemm_skinny_operand_beyond_4gb(ops):
+    """The LDS-DMA form of the K-split kernel addresses its operands with 32-bit byte offsets from the operand base: an
+    operand whose rows span 4 GB or more (here 24 rows 2^27 elements apart in a 6.4 GB buffer) has to take the
+    register-form kernel, with the same result as the compact copy of the same rows."""
+    torch.manual_seed(3)
+    M, N, K = 24, 512, 512
+    stride = 1 << 27
+    big = torch.empty((M - 1) * stride + K, dtype=torch.bfloat16, device="cuda")
+    a = big.as_strided((M, K), (stride, 1))
+    a.copy_(torch.randn(M, K).bfloat16())
+    w = torch.randn(N, K).bfloat16().cuda()
+    ops.start_profile()
+    far = ops.gemm(a, w, True, torch.float32)
+    near = ops.gemm(a.contiguous(), w, True, torch.float32)
+    names = [r["kernel"] for r in ops.stop_profile()]
+    assert names[0].startswith("gemm_skinny_kernel<") and names[1].startswith("gemm_skinny_dma_kernel<"), names
+    assert_close(far, near, 1e-5, "rows 256 MB apart")
+    assert_close(far, a.double() @ w.double().t(), 2e-5 * math.sqrt(K), "against fp64")
+    del big
+
+
 def test_gemm_skinny_beta_accumulates(ops):
     """beta * C_old in the skinny epilogue (the decode backward's dprobs feedback, fp32 output)."""
     torch.manual_seed(5)
